@@ -1,0 +1,396 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (read-only, /root/reference) on CPU.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+
+Only OUTPUTS are written (tests/golden/*.safetensors / *.json): weights (bf16-rounded, random
+init), inputs, per-stage activations, logits, loss, selected grads, greedy token ids, and the
+collator's output for mock_dataset/cat.jpg.  No reference source text is copied.
+
+Import recipe = SURVEY.md Appendix A (three harness-side shims, none edits the reference).
+The numbers pin the semantics of transformers==5.15.0 CLIP / Llama / Qwen2 modules as called
+by the reference at model.py:433-444,517-526,595-640 and image_modality.py:130-137.
+"""
+import io
+import json
+import os
+import sys
+import tempfile
+import types
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+
+import numpy as np
+import torch
+import transformers
+from transformers import (AutoConfig, AutoModel, AutoModelForCausalLM, AutoProcessor,  # noqa: F401
+                          CLIPConfig, CLIPImageProcessorPil, CLIPModel, LlamaConfig,
+                          PreTrainedTokenizerFast, Qwen2Config)
+from safetensors.torch import save_file
+
+REF_SRC = "/root/reference/src/multimeditron"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+# ---- shims (harness side) ----------------------------------------------------------------
+pkg = types.ModuleType("multimeditron")
+pkg.__path__ = [REF_SRC]
+sys.modules["multimeditron"] = pkg
+tv = types.ModuleType("torchvision")
+tvm = types.ModuleType("torchvision.models")
+tv.models = tvm
+sys.modules["torchvision"] = tv
+sys.modules["torchvision.models"] = tvm
+
+from multimeditron.model.model import MultimodalConfig, MultiModalModelForCausalLM, ChatTemplate  # noqa: E402
+import multimeditron.model.modalities.image_modality as im  # noqa: E402
+
+im.AutoImageProcessor = types.SimpleNamespace(from_pretrained=CLIPImageProcessorPil.from_pretrained)
+from multimeditron.model.modalities import ImageConfig  # noqa: E402
+from multimeditron.model.data_loader import DataCollatorForMultimodal  # noqa: E402
+from multimeditron.dataset.loader import FileSystemImageLoader, RawImageLoader  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def bf16_round_(t: torch.Tensor) -> torch.Tensor:
+    return t.copy_(t.to(torch.bfloat16).to(t.dtype))
+
+
+# ---- tiny model directories ----------------------------------------------------------------
+VIS = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+           image_size=56, patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=32)
+TXT = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+           vocab_size=64, max_position_embeddings=16, projection_dim=32)
+VOCAB = 130
+EOS = 129
+IMG_START, IMG_END, ATTACH = 126, 127, 125
+P = (VIS["image_size"] // VIS["patch_size"]) ** 2  # 16
+
+
+def make_clip_dir(d, seed):
+    torch.manual_seed(seed)
+    clip = CLIPModel(CLIPConfig(text_config=TXT, vision_config=VIS, projection_dim=32))
+    # HF inits LayerNorm to (1, 0) and biases to 0; perturb them so the fixtures exercise them.
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in clip.named_parameters():
+            if p.ndim == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    clip.save_pretrained(d)
+    CLIPImageProcessorPil(size={"shortest_edge": VIS["image_size"]},
+                          crop_size={"height": VIS["image_size"], "width": VIS["image_size"]}).save_pretrained(d)
+
+
+def llama_cfg():
+    return LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                       num_key_value_heads=1, head_dim=64, vocab_size=128, rms_norm_eps=1e-5,
+                       max_position_embeddings=131072, tie_word_embeddings=False,
+                       rope_parameters={"rope_type": "llama3", "rope_theta": 500000.0, "factor": 8.0,
+                                        "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                        "original_max_position_embeddings": 8192})
+
+
+def qwen2_cfg():
+    return Qwen2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                       num_key_value_heads=1, vocab_size=128, rms_norm_eps=1e-6, max_position_embeddings=32768,
+                       tie_word_embeddings=True, use_sliding_window=False,
+                       rope_parameters={"rope_type": "default", "rope_theta": 1000000.0})
+
+
+def build_model(llm_cfg, seed, tmp):
+    d1 = os.path.join(tmp, "clip")
+    d2 = os.path.join(tmp, "llm")
+    os.makedirs(d1, exist_ok=True)
+    os.makedirs(d2, exist_ok=True)
+    make_clip_dir(d1, seed)
+    llm_cfg.save_pretrained(d2)
+    torch.manual_seed(seed + 7)
+    cfg = MultimodalConfig(vocab_size=VOCAB, modalities=[ImageConfig(hidden_size=128, clip_name=d1)],
+                           llm_path=d2, dtype="float32", eos_token_idx=EOS, hidden_size=128)
+    model = MultiModalModelForCausalLM(cfg)
+    # Re-randomise everything deterministically (post_init policies differ between HF versions),
+    # then round to bf16-representable values so bf16 and fp32 consumers see identical weights.
+    g = torch.Generator().manual_seed(seed + 11)
+    with torch.no_grad():
+        seen = set()
+        for n, p in model.named_parameters():
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            if "layernorm" in n.lower() or "layer_norm" in n or "layrnorm" in n or n.endswith("norm.weight"):
+                if n.endswith("weight"):
+                    p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif p.ndim == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.06 * torch.randn(p.shape, generator=g))
+            bf16_round_(p)
+    return model.eval()
+
+
+# ---- synthetic batch (hand-built; the collator has its own fixture) ---------------------------
+def make_batch(seed, S, layout, pad_side):
+    """layout: per sample list of image start positions (index of the first attachment token)."""
+    g = torch.Generator().manual_seed(seed)
+    B = len(layout)
+    lengths = [S if b == 0 else S - 7 for b in range(B)] if pad_side != "none" else [S] * B
+    ids = torch.randint(0, 120, (B, S), generator=g)
+    mask = torch.ones(B, S, dtype=torch.long)
+    labels = ids.clone()
+    batch_idx, token_range, pixels = [], [], []
+    for b, starts in enumerate(layout):
+        L = lengths[b]
+        off = S - L if pad_side == "left" else 0
+        if L < S:
+            if pad_side == "left":
+                mask[b, :off] = 0
+                ids[b, :off] = EOS
+            else:
+                mask[b, L:] = 0
+                ids[b, L:] = EOS
+        for s in starts:
+            s = s + off
+            ids[b, s - 1] = IMG_START
+            ids[b, s:s + P] = ATTACH
+            ids[b, s + P] = IMG_END
+            labels[b, s - 1:s + P + 1] = -100
+            batch_idx += [b] * P
+            token_range += list(range(s, s + P))
+            pixels.append(bf16_round_(torch.randn(3, VIS["image_size"], VIS["image_size"], generator=g)))
+        labels[b, off:off + 6] = -100  # masked "user" prefix
+    labels = torch.where(mask == 0, torch.full_like(labels, -100), torch.where(labels == ATTACH, -100, labels))
+    labels[ids == IMG_START] = -100
+    labels[ids == IMG_END] = -100
+    pos = (mask.cumsum(-1) - 1).masked_fill(mask == 0, 0)
+    pmi = {"batch_idx": {"image": torch.tensor(batch_idx, dtype=torch.long)},
+           "token_range": {"image": torch.tensor(token_range, dtype=torch.long)},
+           "stacked": {"image": pixels}}
+    if not pixels:
+        pmi = {"batch_idx": {}, "token_range": {}, "stacked": {}}
+    return dict(input_ids=ids, attention_mask=mask, position_ids=pos, labels=labels,
+                processed_multimodal_inputs=pmi)
+
+
+GRAD_KEYS = ("projector", "model.model.layers.0.", "model.model.embed_tokens", "model.lm_head", "model.model.norm",
+             "vision_model.encoder.layers.1.", "vision_model.embeddings", "vision_model.pre_layrnorm")
+
+
+def run_case(model, batch, tag, out, do_grads=True, do_generate=False):
+    acts = {}
+    hooks = []
+    mod = model.modalities_with_projection[0]
+    vm = mod.feature_extractor.vision_model
+
+    def grab(name, pick=lambda o: o):
+        def fn(_m, _i, o):
+            o = pick(o)
+            acts[name] = o.detach().float().clone()
+        return fn
+
+    has_img = len(batch["processed_multimodal_inputs"]["stacked"]) > 0
+    hooks.append(vm.embeddings.register_forward_hook(grab("vit_embeddings")))
+    hooks.append(vm.pre_layrnorm.register_forward_hook(grab("vit_pre_ln")))
+    hooks.append(vm.encoder.layers[0].register_forward_hook(grab("vit_layer0", lambda o: o[0] if isinstance(o, tuple) else o)))
+    hooks.append(vm.encoder.register_forward_hook(grab("vit_last_hidden", lambda o: o.last_hidden_state)))
+    hooks.append(mod.projector.register_forward_hook(grab("projector_out")))
+    llm = model.model.model
+    hooks.append(llm.layers[0].register_forward_hook(grab("llm_layer0", lambda o: o[0] if isinstance(o, tuple) else o)))
+    hooks.append(llm.norm.register_forward_hook(grab("llm_final_norm")))
+
+    model.unfreeze()
+    model.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        spliced = model.embed_modalities_with_text(batch["input_ids"], batch["processed_multimodal_inputs"])
+    acts["spliced_embeds"] = spliced.float().clone()
+    acts.clear() if False else None
+    o = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+              position_ids=batch["position_ids"], labels=batch["labels"],
+              processed_multimodal_inputs=batch["processed_multimodal_inputs"])
+    for h in hooks:
+        h.remove()
+    out[f"{tag}.logits"] = o.logits.detach().float()
+    out[f"{tag}.loss"] = o.loss.detach().float().reshape(1)
+    for k, v in acts.items():
+        if not has_img and k.startswith(("vit", "proj")):
+            continue
+        out[f"{tag}.act.{k}"] = v
+    if do_grads:
+        o.loss.backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None and any(k in n for k in GRAD_KEYS):
+                out[f"{tag}.grad.{n}"] = p.grad.detach().float().clone()
+        model.zero_grad(set_to_none=True)
+    for k in ("input_ids", "attention_mask", "position_ids", "labels"):
+        out[f"{tag}.in.{k}"] = batch[k].clone()
+    pmi = batch["processed_multimodal_inputs"]
+    if has_img:
+        out[f"{tag}.in.batch_idx"] = pmi["batch_idx"]["image"].clone()
+        out[f"{tag}.in.token_range"] = pmi["token_range"]["image"].clone()
+        out[f"{tag}.in.pixels"] = torch.stack(pmi["stacked"]["image"]).clone()
+    if do_generate:
+        for T in (0.1, 0.7):
+            with torch.no_grad():
+                ids = model.generate(batch, max_new_tokens=8, temperature=T, do_sample=False)
+            out[f"{tag}.greedy_T{T}"] = ids.clone()
+
+
+def model_fixture(name, llm_cfg, seed):
+    with tempfile.TemporaryDirectory() as tmp:
+        model = build_model(llm_cfg, seed, tmp)
+        out = {}
+        run_case(model, make_batch(seed + 1, 48, [[3], [2, 24]], "right"), "right", out)
+        run_case(model, make_batch(seed + 2, 48, [[4], [2, 22]], "left"), "left", out, do_grads=False, do_generate=True)
+        run_case(model, make_batch(seed + 3, 40, [[], []], "none"), "textonly", out, do_grads=False, do_generate=True)
+        run_case(model, make_batch(seed + 4, 80, [[2, 21, 40, 60]], "none"), "interleaved4", out, do_grads=False)
+        # weights (only what the hot path uses: vision tower, projector, LLM)
+        w = {}
+        for n, p in model.state_dict().items():
+            if "text_model" in n or "text_projection" in n or "visual_projection" in n or "logit_scale" in n \
+                    or "position_ids" in n or "post_layernorm" in n:
+                continue
+            w[n] = p.detach().to(torch.bfloat16).contiguous().clone()
+        save_file(w, os.path.join(OUT, f"{name}.weights.safetensors"))
+        save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(OUT, f"{name}.vectors.safetensors"))
+        meta = dict(name=name, vision=VIS, llm=llm_cfg.to_dict(), vocab_size=VOCAB, eos_token_idx=EOS,
+                    image_start=IMG_START, image_end=IMG_END, attachment=ATTACH, num_patches=P,
+                    transformers=transformers.__version__, torch=torch.__version__,
+                    cases=sorted({k.split(".")[0] for k in out}))
+        meta["llm"] = {k: v for k, v in meta["llm"].items()
+                       if isinstance(v, (int, float, str, bool, dict, type(None), list))}
+        with open(os.path.join(OUT, f"{name}.meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True, default=str)
+        print(name, "weights", sum(v.numel() for v in w.values()), "vector tensors", len(out))
+
+
+# ---- collator fixture ------------------------------------------------------------------------
+LLAMA3_TEMPLATE = (
+    "{% for message in messages %}"
+    "{{ '<|start_header_id|> ' + message['role'] + ' <|end_header_id|> ' + message['content'] + ' <|eot_id|> ' }}"
+    "{% endfor %}"
+    "{% if add_generation_prompt %}{{ '<|start_header_id|> assistant <|end_header_id|> ' }}{% endif %}")
+
+WORDS = ("<|eot_id|> <|start_header_id|> <|end_header_id|> <|image_start|> <|image_end|> <|attachment|> <unk> "
+         "system user assistant describe the image in detail what is this a cat sitting on grass it looks at "
+         "camera you are helpful and there two pictures first second nice").split()
+
+
+def make_tokenizer():
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    vocab = {w: i for i, w in enumerate(WORDS)}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    t = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|eot_id|>", unk_token="<unk>",
+                                additional_special_tokens=["<|start_header_id|>", "<|end_header_id|>",
+                                                           "<|image_start|>", "<|image_end|>", "<|attachment|>"],
+                                chat_template=LLAMA3_TEMPLATE)
+    t.pad_token = t.eos_token
+    return t
+
+
+def llama_spaced_template():
+    # The synthetic WordLevel tokenizer splits on whitespace, so role tags carry spaces.
+    ct = ChatTemplate.llama()
+    for role in ct.delimiters:
+        ct.delimiters[role] = {"start": f"<|start_header_id|> {role} <|end_header_id|>", "end": "<|eot_id|>"}
+    return ct
+
+
+def collator_fixture():
+    from PIL import Image
+    with tempfile.TemporaryDirectory() as tmp:
+        make_clip_dir(tmp, 5)
+        proc = im.ImageProcessor(ImageConfig(hidden_size=128, clip_name=tmp))
+        cat = "/root/reference/mock_dataset/cat.jpg"
+        with open(cat, "rb") as f:
+            cat_bytes = f.read()
+        out = {}
+        meta = {"words": WORDS, "chat_template": LLAMA3_TEMPLATE, "attachment_token": "<|attachment|>",
+                "image_size": VIS["image_size"], "patch_size": VIS["patch_size"], "cases": {}}
+        samples_conv = [
+            {"conversations": [{"role": "system", "content": "you are helpful"},
+                               {"role": "user", "content": "<|attachment|> describe the image in detail"},
+                               {"role": "assistant", "content": "a cat sitting on grass"}],
+             "modalities": [{"type": "image", "value": "cat.jpg"}]},
+            {"conversations": [{"role": "user", "content": "what is this"},
+                               {"role": "assistant", "content": "nice"}],
+             "modalities": []},
+            {"conversations": [{"role": "user", "content": "first <|attachment|> and second <|attachment|> what is this"},
+                               {"role": "assistant", "content": "two pictures"},
+                               {"role": "user", "content": "describe the first"},
+                               {"role": "assistant", "content": "it looks at the camera"}],
+             "modalities": [{"type": "image", "value": "cat.jpg"}, {"type": "image", "value": "EPFL_campus_2017.jpg"}]},
+        ]
+        for side in ("right", "left"):
+            for gen in (False, True):
+                tok = make_tokenizer()
+                tok.padding_side = side
+                coll = DataCollatorForMultimodal(tokenizer=tok, modality_processors={"image": proc},
+                                                 modality_loaders={"image": FileSystemImageLoader("/root/reference/mock_dataset")},
+                                                 attachment_token="<|attachment|>", chat_template=llama_spaced_template(),
+                                                 add_generation_prompt=gen)
+                import copy
+                b = coll(copy.deepcopy(samples_conv))
+                tag = f"conv_{side}_gen{int(gen)}"
+                for k in ("input_ids", "labels", "attention_mask", "position_ids"):
+                    out[f"{tag}.{k}"] = b[k].clone()
+                out[f"{tag}.batch_idx"] = b["processed_multimodal_inputs"]["batch_idx"]["image"].clone()
+                out[f"{tag}.token_range"] = b["processed_multimodal_inputs"]["token_range"]["image"].clone()
+                out[f"{tag}.pixels"] = torch.stack(b["processed_multimodal_inputs"]["stacked"]["image"]).clone()
+                meta["cases"][tag] = {"padding_side": side, "add_generation_prompt": gen, "kind": "conversations"}
+        # text samples through the raw-image (bytes) loader
+        tok = make_tokenizer()
+        tok.padding_side = "right"
+        coll = DataCollatorForMultimodal(tokenizer=tok, modality_processors={"image": proc},
+                                         modality_loaders={"image": RawImageLoader()},
+                                         attachment_token="<|attachment|>", chat_template=llama_spaced_template())
+        samples_text = [{"text": "a cat <|attachment|> sitting on grass", "modalities": [{"type": "image", "value": {"bytes": cat_bytes}}]},
+                        {"text": "what is this", "modalities": []}]
+        try:
+            b = coll(samples_text)
+            tag = "text_right"
+            for k in ("input_ids", "labels", "attention_mask", "position_ids"):
+                out[f"{tag}.{k}"] = b[k].clone()
+            out[f"{tag}.batch_idx"] = b["processed_multimodal_inputs"]["batch_idx"]["image"].clone()
+            out[f"{tag}.token_range"] = b["processed_multimodal_inputs"]["token_range"]["image"].clone()
+            out[f"{tag}.pixels"] = torch.stack(b["processed_multimodal_inputs"]["stacked"]["image"]).clone()
+            meta["cases"][tag] = {"padding_side": "right", "kind": "text"}
+        except Exception as e:  # the reference's text branch tokenizes a ragged batch with return_tensors="pt"
+            meta["text_branch_error"] = f"{type(e).__name__}: {e}"[:300]
+            # one-sample text batch (no raggedness)
+            b = coll(samples_text[:1])
+            tag = "text_single"
+            for k in ("input_ids", "labels", "attention_mask", "position_ids"):
+                out[f"{tag}.{k}"] = b[k].clone()
+            out[f"{tag}.batch_idx"] = b["processed_multimodal_inputs"]["batch_idx"]["image"].clone()
+            out[f"{tag}.token_range"] = b["processed_multimodal_inputs"]["token_range"]["image"].clone()
+            out[f"{tag}.pixels"] = torch.stack(b["processed_multimodal_inputs"]["stacked"]["image"]).clone()
+            meta["cases"][tag] = {"padding_side": "right", "kind": "text"}
+        meta["samples_conv"] = samples_conv
+        meta["samples_text"] = [{"text": s["text"], "n_images": len(s["modalities"])} for s in samples_text]
+        save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(OUT, "collator.vectors.safetensors"))
+        with open(os.path.join(OUT, "collator.meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        # the two mock images are DATA held by the reference's repo; tests need them as inputs
+        import shutil
+        os.makedirs(os.path.join(OUT, "mock_dataset"), exist_ok=True)
+        for fn in ("cat.jpg", "EPFL_campus_2017.jpg"):
+            shutil.copyfile(os.path.join("/root/reference/mock_dataset", fn), os.path.join(OUT, "mock_dataset", fn))
+        print("collator cases", list(meta["cases"]))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["llama", "qwen2", "collator"]
+    if "llama" in which:
+        model_fixture("tiny_clip_llama", llama_cfg(), 100)
+    if "qwen2" in which:
+        model_fixture("tiny_clip_qwen2", qwen2_cfg(), 200)
+    if "collator" in which:
+        collator_fixture()
