@@ -1,0 +1,168 @@
+/*
+ * mm_hip.h -- C ABI of libmmhip.so: the MI355X (gfx950) kernels under the MultiMeditron
+ * multimodal hot path  (modality encoder -> projector -> embed-splice -> LLM decoder, fwd+bwd).
+ *
+ * The reference (leagrieder/MultiMeditron) has no FFI: its operator boundary for this path is a
+ * set of Python/torch calls.  Each entry point below replaces the torch/HF call(s) cited next to
+ * it (paths under /root/reference/src/multimeditron/, `HF:` = transformers 5.15.0).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a row-major buffer; no torch types cross the ABI
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised
+ *   - nothing is allocated inside; the caller provides outputs and workspaces
+ *   - return value: 0 = MM_OK, negative = error (mm_error_string); no exceptions, no aborts
+ *   - dtype: MM_BF16 (storage bf16, fp32 accumulate) or MM_F32 (exact fp32; parity path)
+ */
+#ifndef MM_HIP_H
+#define MM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MM_BF16 = 0, MM_F32 = 1 } mm_dtype;
+
+enum { MM_OK = 0, MM_ERR_ARG = -1, MM_ERR_ALIGN = -2, MM_ERR_UNSUPPORTED = -3, MM_ERR_LAUNCH = -4 };
+
+/* GEMM operand layouts.  C is always [M,N] row-major (ldc). */
+enum {
+  MM_GEMM_NT = 0, /* A[M,K] (lda), B[N,K] (ldb): y = x W^T      -- nn.Linear forward            */
+  MM_GEMM_NN = 1, /* A[M,K] (lda), B[K,N] (ldb): dx = dy W      -- nn.Linear input gradient     */
+  MM_GEMM_TN = 2  /* A[K,M] (lda), B[K,N] (ldb): dW = dy^T x    -- nn.Linear weight gradient    */
+};
+
+/* GEMM epilogue flags (OR-ed) */
+enum {
+  MM_EPI_BIAS = 1,       /* + bias[N]                                      */
+  MM_EPI_GELU_ERF = 2,   /* exact GELU (projectors/mlp.py:35,37)           */
+  MM_EPI_QUICK_GELU = 4, /* x*sigmoid(1.702x) (HF:activations.py:117-123)  */
+  MM_EPI_RESIDUAL = 8,   /* + residual[M,N] (ldr)                          */
+  MM_EPI_ACCUMULATE = 16 /* C += result (gradient accumulation)            */
+};
+
+int mm_version(void);
+const char* mm_error_string(int code);
+
+/* ---- GEMM: every nn.Linear / Conv2d(k=s) on the path -------------------------------------
+ * replaces F.linear in mlp.py:33-39, HF:clip:280-384 (q/k/v/out/fc1/fc2), HF:clip:152-158 (patch conv as
+ * GEMM), HF:llama:163-176,232-244,480 (gate/up/down, q/k/v/o, lm_head) and their autograd backward.
+ * Requirements: lda, ldb, ldc, ldr multiples of 8 elements; pointers 16-byte aligned; for a K-contiguous
+ * operand whose K is not a multiple of 8 the row padding up to the next multiple of 8 must hold zeros.   */
+int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+            void* C, int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream);
+
+/* column sums: out[N] (+)= sum_m X[m,n]   (bias gradients)                                           */
+int mm_colsum(int dtype, const void* X, int M, int N, int ldx, void* out, int accumulate, void* stream);
+
+/* ---- embed + modality splice: model.py:433-444 ---------------------------------------------------
+ * out[t,:] = proj[src[t],:] if src[t] >= 0 else emb[ids[t],:]; src is built from (batch_idx, token_range)
+ * by mm_splice_build_map (last writer wins, like index_put).                                         */
+int mm_splice_build_map(const int64_t* batch_idx, const int64_t* token_range, int n_mod, int S, int T,
+                        int32_t* src_map, void* stream);
+int mm_embed_splice_fwd(int dtype, const void* emb, int64_t vocab, int H, const int64_t* ids, const void* proj,
+                        const int32_t* src_map, int T, void* out, void* stream);
+/* backward: dproj[i,:] = dE[pos(i),:]; demb[ids[t],:] += dE[t,:] for tokens that were NOT overwritten */
+int mm_embed_splice_bwd(int dtype, const void* dE, int H, const int64_t* ids, const int32_t* src_map, int T,
+                        const int64_t* batch_idx, const int64_t* token_range, int n_mod, int S, void* dproj,
+                        void* demb, int64_t vocab, void* stream);
+
+/* ---- ViT patch embedding glue: HF:clip:138-218 -----------------------------------------------------
+ * patchify: pixels f32 [n,3,Himg,Wimg] -> patches [n*P, Kpad] (k = c*ps*ps + py*ps + px, zero padded)     */
+int mm_patchify(int dtype, const float* pixels, int n, int himg, int wimg, int ps, int kpad, void* patches, void* stream);
+/* x[n,0,:] = cls + pos[0]; x[n,1+p,:] = patch_out[n*P+p,:] + pos[1+p]                                    */
+int mm_vit_embed_fwd(int dtype, const void* patch_out, const void* cls, const void* pos, int n, int P, int D,
+                     void* x, void* stream);
+/* dpatch_out = dx[:,1:,:]; dcls (+)= sum_n dx[n,0]; dpos (+)= sum_n dx[n]                                  */
+int mm_vit_embed_bwd(int dtype, const void* dx, int n, int P, int D, void* dpatch_out, void* dcls, void* dpos,
+                     int accumulate, void* stream);
+/* dst[n,P,D] = src[n,1+P,D][:,1:,:] (image_modality.py:133) and its adjoint (zero CLS row)                */
+int mm_drop_cls_fwd(int dtype, const void* src, int n, int P, int D, void* dst, void* stream);
+int mm_drop_cls_bwd(int dtype, const void* ddst, int n, int P, int D, void* dsrc, void* stream);
+
+/* ---- norms ------------------------------------------------------------------------------------------
+ * RMSNorm: HF:llama:53-70.  rstd[M] f32 is saved for backward.                                            */
+int mm_rmsnorm_fwd(int dtype, const void* x, const void* w, int M, int H, float eps, void* y, float* rstd, void* stream);
+/* dx = rstd*(g - xhat*mean(g*xhat)), g = dy*w;  dw_partial[nblk,H] f32 (nblk = mm_norm_bwd_blocks(M))        */
+int mm_rmsnorm_bwd(int dtype, const void* dy, const void* x, const void* w, const float* rstd, int M, int H,
+                   void* dx, float* dw_partial, void* stream);
+/* LayerNorm: HF:clip:338-339,608 (nn.LayerNorm).  mean/rstd [M] f32 saved.                                 */
+int mm_layernorm_fwd(int dtype, const void* x, const void* w, const void* b, int M, int H, float eps, void* y,
+                     float* mean, float* rstd, void* stream);
+int mm_layernorm_bwd(int dtype, const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
+                     int M, int H, void* dx, float* dw_partial, float* db_partial, void* stream);
+int mm_norm_bwd_blocks(int M);
+/* out[H] (+)= sum_b partial[b,H]  (f32 partials -> param-dtype gradient)                                    */
+int mm_reduce_partials(int dtype, const float* partial, int nblk, int H, void* out, int accumulate, void* stream);
+
+/* ---- RoPE: HF:llama:113-160 (rotate_half form) --------------------------------------------------------
+ * cos/sin tables [T, D/2] f32 from position_ids and inv_freq (HF:llama:113-127; llama3 scaling is applied by
+ * the caller to inv_freq, HF:modeling_rope_utils.py:641-662).  round_bf16: round cos/sin to bf16 (HF casts them
+ * to the activation dtype).                                                                               */
+int mm_rope_table(const int64_t* position_ids, const float* inv_freq, int T, int half, int round_bf16, float* cos_t,
+                  float* sin_t, void* stream);
+/* in place on x viewed as [T, nheads, D] with row stride ld (elements); inverse=1 applies the adjoint          */
+int mm_rope_apply(int dtype, void* x, int T, int nheads, int D, int ld, const float* cos_t, const float* sin_t,
+                  int inverse, void* stream);
+
+/* ---- attention: HF:llama:191-213 (eager softmax attention, GQA via repeat_kv), HF:clip:280-334 ------------
+ * q [B,Sq,Hq,D], k/v [B,Skv,Hkv,D] with element strides (batch, seq, head); D contiguous; D in {64,128} for
+ * MM_BF16 (MFMA path), any D<=256 for MM_F32.  key_mask [B,Skv] int64 (1 = attend) or NULL.  causal aligns the
+ * LAST query with the LAST key (q position = i + Skv - Sq).  out [B,Sq,Hq,D] contiguous; lse [B,Hq,Sq] f32.     */
+int mm_attn_fwd(int dtype, const void* q, const void* k, const void* v, int B, int Sq, int Skv, int Hq, int Hkv, int D,
+                int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb,
+                int64_t v_ss, int64_t v_sh, const int64_t* key_mask, int causal, float scale, void* out, float* lse,
+                void* stream);
+/* dq/dk/dv use the SAME strides as q/k/v.  delta [B,Hq,Sq] f32 workspace.  dk/dv are overwritten.
+ * For MM_F32 dk/dv must be zero-filled by the caller (atomic accumulation).                                   */
+int mm_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                int B, int Sq, int Skv, int Hq, int Hkv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, const int64_t* key_mask, int causal,
+                float scale, void* dq, void* dk, void* dv, float* delta, void* stream);
+
+/* ---- activations -----------------------------------------------------------------------------------------
+ * SwiGLU: HF:llama:163-176.  gu [M, 2I] = [gate | up] from the fused gate/up GEMM; out [M,I] = silu(gate)*up     */
+int mm_swiglu_fwd(int dtype, const void* gu, int M, int I, void* out, void* stream);
+int mm_swiglu_bwd(int dtype, const void* gu, const void* dout, int M, int I, void* dgu, void* stream);
+/* kind: 0 = erf GELU (mlp.py:35,37), 1 = quick GELU (HF:clip fc1).  x is the pre-activation.                       */
+int mm_gelu_fwd(int dtype, int kind, const void* x, int64_t n, void* y, void* stream);
+int mm_gelu_bwd(int dtype, int kind, const void* x, const void* dy, int64_t n, void* dx, void* stream);
+/* y = a + b (residual adds that are not fused into a GEMM epilogue)                                             */
+int mm_add(int dtype, const void* a, const void* b, int64_t n, void* y, void* stream);
+
+/* ---- loss: HF:loss/loss_utils.py:36-71 --------------------------------------------------------------------------
+ * logits [T, ld] (V valid columns); labels already shifted by the caller; ignore_index = -100.
+ * fwd: lse[T] f32, loss_row[T] f32 (0 for ignored rows).  loss = sum(loss_row)/count is reduced by mm_ce_reduce.    */
+int mm_ce_fwd(int dtype, const void* logits, int T, int V, int ld, const int64_t* labels, float* lse, float* loss_row, void* stream);
+/* out[0] = sum(loss_row)/max(count,1), out[1] = count (number of labels != -100)                                   */
+int mm_ce_reduce(const float* loss_row, const int64_t* labels, int T, float* out, void* stream);
+/* dlogits[t,v] = (exp(logit - lse[t]) - [v==label]) * gscale[0] / count, 0 for ignored rows and for v in [V, ld)    */
+int mm_ce_bwd(int dtype, const void* logits, int T, int V, int ld, const int64_t* labels, const float* lse,
+              const float* loss_and_count, const float* gscale, void* dlogits, void* stream);
+/* next-token selection of model.py:607-621: argmax(softmax(logits/T)) over the LAST dim, first max wins          */
+int mm_argmax_softmax(int dtype, const void* logits, int rows, int V, int ld, float temperature, int64_t* out, void* stream);
+
+/* ---- optimizer: AdamW (config_alignment.yaml:38-59 -> torch.optim.AdamW semantics) + grad-norm clip ----------------
+ * sumsq partial: out[blk] = sum g^2 over a slice; mm_gradnorm_finish: total[0] = sqrt(sum) ; clip coef in total[1]  */
+int mm_gradnorm_partial(int dtype, const void* g, int64_t n, float* partial, int nblk, void* stream);
+int mm_gradnorm_finish(const float* partial, int nblk, float max_norm, float* total, void* stream);
+/* p (param dtype), g (param dtype), master/m/v f32.  clip = device scalar (total+1) or NULL.                          */
+int mm_adamw_step(int dtype, void* p, const void* g, float* master, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, const float* clip, void* stream);
+
+/* ---- utilities ---------------------------------------------------------------------------------------------------- */
+int mm_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
+int mm_fill_zero(void* p, int64_t bytes, void* stream);
+
+/* ---- diagnostics (tests only): raw lane maps of ds_read_b64_tr_b16 and the bf16 MFMAs ------------------------------
+ * tr_read: img = 4096 bf16 copied to LDS; lane l reads at byte address addr[l]; out[l*4+j] = its j-th element.
+ * mfma: shape 32 -> v_mfma_f32_32x32x16_bf16 (out 64x16 f32), 16 -> v_mfma_f32_16x16x32_bf16 (out 64x4 f32);
+ *       a/b = 64 lanes x 8 bf16 fragments.                                                                         */
+int mm_debug_tr_read(const void* img_bf16_4096, const void* lane_byte_addr_i32_64, void* out_bf16_256, void* stream);
+int mm_debug_mfma(int shape, const void* a_frag_bf16_512, const void* b_frag_bf16_512, void* out_f32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM_HIP_H */

@@ -1,0 +1,707 @@
+// Flash-style attention for the Llama/Qwen2 decoder (causal, GQA, key-padding mask) and the CLIP ViT
+// (non-causal), forward + backward, on v_mfma_f32_32x32x16_bf16.
+//
+// Layout idea (CDNA4): every product is issued "key-major" so that the quantity a row-softmax reduces
+// over lives in a lane's OWN registers and the query index lives on the lane:
+//   S^T[key][q] = K . Q^T          (A = K fragment from LDS, B = Q fragment held in registers)
+//   O^T[d][q]  += V^T[d][key] . P^T (A = V^T by ds_read_b64_tr_b16 from a row-major V tile,
+//                                    B = P^T taken straight from the S^T accumulators: no LDS, no shuffles)
+// so max/sum over keys are 31 in-register ops + one cross-half exchange, the online-softmax rescale is one
+// scalar per lane, and the backward dQ kernel has the same shape (dQ^T += K^T . dS^T).
+// dK/dV use a second kernel, one workgroup per 128 keys, that keeps dK^T/dV^T of 32 keys per wave in
+// accumulators while sweeping the query tiles (no atomics, deterministic).
+// K tiles sit in LDS as [d/8][key][8] (ds_read_b128, conflict free); V / transposed operands as
+// row-major tiles with a 32-byte XOR swizzle chosen so the transposed reads are conflict free.
+//
+// fp32 variants (parity path only) are plain wave-per-query-row kernels.
+#include "mm_common.h"
+
+namespace {
+
+struct AttnArgs {
+  const void *q, *k, *v;
+  int B, Sq, Skv, Hq, Hkv;
+  int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh;
+  const int64_t* kmask;
+  int causal;
+  float scale;
+  void* out;
+  float* lse;
+  // backward
+  const void* dout;
+  const float* delta;
+  void *dq, *dk, *dv;
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int D> __device__ __forceinline__ int v_swz(int row) {
+  if constexpr (D == 128) return (row & 3) << 1;
+  else return ((row >> 1) & 1) << 1;
+}
+
+// ---- tile staging (256 threads) ---------------------------------------------------------------------------
+// KC image: [D/8][ROWS][8]; loads 16 B per lane, 8 rows x 8 chunks (full 128-B lines) per wave instruction
+template <int D, int ROWS>
+struct KcStage {
+  static constexpr int NI = ROWS * (D / 8) / 256;
+  u32x4 r[NI];
+  __device__ __forceinline__ void load(const bf16* base, int64_t row_stride, int row0, int nrows_valid) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int HALVES = D / 64;  // 8-chunk groups per row
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int u = w * NI + i;
+      const int rg = u / HALVES, dh = u % HALVES;
+      const int row = rg * 8 + (l & 7), dc = dh * 8 + (l >> 3);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row0 + row < nrows_valid) v = *(const u32x4*)(base + (int64_t)(row0 + row) * row_stride + dc * 8);
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(char* tile) const {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int HALVES = D / 64;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int u = w * NI + i;
+      const int rg = u / HALVES, dh = u % HALVES;
+      const int row = rg * 8 + (l & 7), dc = dh * 8 + (l >> 3);
+      *(u32x4*)(tile + (dc * ROWS + row) * 16) = r[i];
+    }
+  }
+  // same registers into the row-major swizzled (KS) image; 2-way write conflicts only
+  __device__ __forceinline__ void store_rowmajor(char* tile) const {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int HALVES = D / 64;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int u = w * NI + i;
+      const int rg = u / HALVES, dh = u % HALVES;
+      const int row = rg * 8 + (l & 7), c16 = dh * 8 + (l >> 3);
+      *(u32x4*)(tile + row * (D * 2) + (((c16 >> 1) ^ v_swz<D>(row)) * 32) + (c16 & 1) * 16) = r[i];
+    }
+  }
+};
+
+// KS image: [ROWS][D] row-major with 32-byte-chunk XOR swizzle
+template <int D, int ROWS>
+struct KsStage {
+  static constexpr int CPR = D / 8;  // 16-B chunks per row
+  static constexpr int NI = ROWS * CPR / 256;
+  u32x4 r[NI];
+  __device__ __forceinline__ void load(const bf16* base, int64_t row_stride, int row0, int nrows_valid) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int idx = i * 256 + threadIdx.x;
+      const int row = idx / CPR, c16 = idx % CPR;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row0 + row < nrows_valid) v = *(const u32x4*)(base + (int64_t)(row0 + row) * row_stride + c16 * 8);
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(char* tile) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int idx = i * 256 + threadIdx.x;
+      const int row = idx / CPR, c16 = idx % CPR;
+      *(u32x4*)(tile + row * (D * 2) + (((c16 >> 1) ^ v_swz<D>(row)) * 32) + (c16 & 1) * 16) = r[i];
+    }
+  }
+  // re-tile the same registers (loaded with KsStage::load's mapping) is not possible for KC; see callers
+};
+
+// A fragment (32 rows x 16 k) from a KC image: lane row = l&31, k = 8*(l>>5)+j
+template <int ROWS>
+__device__ __forceinline__ bf16x8 kc_frag(const char* tile, int rblk, int kstep) {
+  const int l = threadIdx.x & 63;
+  return *(const bf16x8*)(tile + ((kstep * 2 + (l >> 5)) * ROWS + rblk * 32 + (l & 31)) * 16);
+}
+
+// A fragment of the TRANSPOSE of a row-major KS image [rows = k index][D]: A[row = d][k], for d-block db
+// (32 wide) and k rows kbase .. kbase+15 in the accumulator-compatible order
+//   element j of lane half h  <->  k row  kbase + 8*(j>>2) + 4*h + (j&3)
+template <int D>
+__device__ __forceinline__ bf16x8 ks_frag_t(const char* tile, int db, int kbase) {
+  const int l = threadIdx.x & 63;
+  const int h = l >> 5, gi = (l >> 4) & 1, i = l & 15, q = i >> 2, p = i & 3;
+  const int row1 = kbase + 4 * h + q;
+  const int c32 = db * 2 + gi;
+  const int sw = ((c32 ^ v_swz<D>(row1)) * 32) + p * 8;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + row1 * (D * 2) + sw));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + (row1 + 8) * (D * 2) + sw));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+
+// B fragment (k = d, n = row) straight from global: lane n = l&31, d = dstep*16 + 8*(l>>5) .. +7
+__device__ __forceinline__ bf16x8 row_frag_global(const bf16* row_ptr_or_null, int dstep) {
+  const int l = threadIdx.x & 63;
+  bf16x8 z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+  if (!row_ptr_or_null) return z;
+  return *(const bf16x8*)(row_ptr_or_null + dstep * 16 + 8 * (l >> 5));
+}
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ============================================================================================================
+// forward
+// ============================================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int BKV = 64, NDS = D / 16, NDB = D / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kt = smem;                 // KC image [D/8][64][8]
+  char* Vt = smem + BKV * D * 2;   // KS image [64][D]
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
+  const int b = blockIdx.z, hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int qi = q0 + (l & 31);
+  const int shift = a.Skv - a.Sq;  // causal: query i sees keys <= i + shift
+  const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
+  const bf16* K = (const bf16*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const bf16* V = (const bf16*)a.v + b * a.v_sb + hkv * a.v_sh;
+
+  bf16x8 qf[NDS];
+  {
+    const bf16* qrow = qi < a.Sq ? Q + (int64_t)qi * a.q_ss : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) qf[ds] = row_frag_global(qrow, ds);
+  }
+  f32x16 o_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc = a.scale * LOG2E;
+
+  int ntiles = (a.Skv + BKV - 1) / BKV;
+  if (a.causal) {
+    const int qmax = min(a.Sq - 1, (int)blockIdx.x * 128 + 127) + shift;
+    ntiles = min(ntiles, qmax / BKV + 1);
+    if (qmax < 0) ntiles = 0;
+  }
+  KcStage<D, BKV> ks;
+  KsStage<D, BKV> vs;
+  if (ntiles > 0) {
+    ks.load(K, a.k_ss, 0, a.Skv);
+    vs.load(V, a.v_ss, 0, a.Skv);
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * BKV;
+    __syncthreads();
+    ks.store(Kt);
+    vs.store(Vt);
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      ks.load(K, a.k_ss, kv0 + BKV, a.Skv);
+      vs.load(V, a.v_ss, kv0 + BKV, a.Skv);
+    }
+    // key validity for this tile: one key per lane -> 64-bit ballot
+    bool kvalid = (kv0 + l) < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + kv0 + l] != 0;
+    const unsigned long long kbits = __ballot(kvalid);
+    const bool need_mask = (kbits != ~0ull) || (a.causal && (kv0 + BKV - 1) > (q0 + shift));
+
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds)
+        s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BKV>(Kt, kb, ds), qf[ds], s_acc[kb], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float tv = s_acc[kb][r] * sc;
+        if (need_mask) {
+          const int kl = kb * 32 + acc_row(r, h);
+          bool ok = (kbits >> kl) & 1ull;
+          if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
+          tv = ok ? tv : -INFINITY;
+        }
+        s_acc[kb][r] = tv;
+        mx = fmaxf(mx, tv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_safe);
+    float rs = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(s_acc[kb][r] - m_safe);
+        rs += p;
+        pf[kb][r >> 3][r & 7] = (bf16)p;
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks_frag_t<D>(Vt, db, kb * 32 + s * 16), pf[kb][s], o_acc[db], 0, 0, 0);
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qi < a.Sq) {
+    bf16* orow = (bf16*)a.out + (((int64_t)b * a.Sq + qi) * a.Hq + hq) * D;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(o_acc[db][rg * 4 + e] * inv);
+        *(bf16x4*)(orow + db * 32 + 8 * rg + 4 * h) = o;
+      }
+    if (h == 0) a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : INFINITY;
+  }
+}
+
+// delta[b,h,q] = sum_d dO*O
+template <typename T>
+__global__ void attn_delta_kernel(const T* o, const T* dout, int B, int Sq, int Hq, int D, float* delta) {
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)B * Sq * Hq;
+  if (wave >= total) return;
+  const int hq = wave % Hq;
+  const int64_t bs = wave / Hq;
+  const int qi = (int)(bs % Sq);
+  const int b = (int)(bs / Sq);
+  const T* op = o + (int64_t)wave * D;
+  const T* dp = dout + (int64_t)wave * D;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += to_f32(op[d]) * to_f32(dp[d]);
+  s = wave_sum(s);
+  if (lane == 0) delta[((int64_t)b * Hq + hq) * Sq + qi] = s;
+}
+
+// ============================================================================================================
+// backward: dQ   (same shape as forward; dQ^T[d][q] += K^T[d][key] . dS^T[key][q])
+// ============================================================================================================
+template <int D>
+__global__ __launch_bounds__(256, (D == 128 ? 1 : 2)) void attn_bwd_dq_kernel(AttnArgs a) {
+  constexpr int BKV = 64, NDS = D / 16, NDB = D / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kc = smem;                      // K, KC image
+  char* Vc = smem + BKV * D * 2;        // V, KC image
+  char* Kr = smem + 2 * BKV * D * 2;    // K, row-major swizzled (for K^T fragments)
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
+  const int b = blockIdx.z, hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int qi = q0 + (l & 31);
+  const int shift = a.Skv - a.Sq;
+  const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
+  const bf16* K = (const bf16*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const bf16* V = (const bf16*)a.v + b * a.v_sb + hkv * a.v_sh;
+  const bf16* dO = (const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * D;
+
+  bf16x8 qf[NDS], dof[NDS];
+  {
+    const bf16* qrow = qi < a.Sq ? Q + (int64_t)qi * a.q_ss : nullptr;
+    const bf16* drow = qi < a.Sq ? dO + (int64_t)qi * a.Hq * D : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+      qf[ds] = row_frag_global(qrow, ds);
+      dof[ds] = row_frag_global(drow, ds);
+    }
+  }
+  const float sc = a.scale * LOG2E;
+  float lse2 = INFINITY, dlt = 0.f;
+  if (qi < a.Sq) {
+    lse2 = a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] * LOG2E;
+    dlt = a.delta[((int64_t)b * a.Hq + hq) * a.Sq + qi];
+  }
+  f32x16 dq_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq_acc[i][r] = 0.f;
+
+  int ntiles = (a.Skv + BKV - 1) / BKV;
+  if (a.causal) {
+    const int qmax = min(a.Sq - 1, (int)blockIdx.x * 128 + 127) + shift;
+    ntiles = min(ntiles, qmax / BKV + 1);
+    if (qmax < 0) ntiles = 0;
+  }
+  KcStage<D, BKV> kcs, vcs;
+  if (ntiles > 0) {
+    kcs.load(K, a.k_ss, 0, a.Skv);
+    vcs.load(V, a.v_ss, 0, a.Skv);
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * BKV;
+    __syncthreads();
+    kcs.store(Kc);
+    vcs.store(Vc);
+    kcs.store_rowmajor(Kr);
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      kcs.load(K, a.k_ss, kv0 + BKV, a.Skv);
+      vcs.load(V, a.v_ss, kv0 + BKV, a.Skv);
+    }
+    bool kvalid = (kv0 + l) < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + kv0 + l] != 0;
+    const unsigned long long kbits = __ballot(kvalid);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s_acc, dp_acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) {
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BKV>(Kc, kb, ds), qf[ds], s_acc, 0, 0, 0);
+        dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BKV>(Vc, kb, ds), dof[ds], dp_acc, 0, 0, 0);
+      }
+      bf16x8 dsf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = kb * 32 + acc_row(r, h);
+        bool ok = (kbits >> kl) & 1ull;
+        if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
+        const float p = ok ? exp2f(s_acc[r] * sc - lse2) : 0.f;
+        const float dsv = p * (dp_acc[r] - dlt) * a.scale;
+        dsf[r >> 3][r & 7] = (bf16)dsv;
+      }
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          dq_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks_frag_t<D>(Kr, db, kb * 32 + s * 16), dsf[s], dq_acc[db], 0, 0, 0);
+    }
+  }
+  if (qi < a.Sq) {
+    bf16* drow = (bf16*)a.dq + b * a.q_sb + hq * a.q_sh + (int64_t)qi * a.q_ss;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)dq_acc[db][rg * 4 + e];
+        *(bf16x4*)(drow + db * 32 + 8 * rg + 4 * h) = o;
+      }
+  }
+}
+
+// ============================================================================================================
+// backward: dK, dV.  One workgroup = 128 keys of one (batch, kv head); wave w owns keys w*32..w*32+31 and keeps
+// dK^T, dV^T [d][key] in accumulators while sweeping (q head in group) x (32-row query tiles).
+//   S[q][key] = Q K^T, dP[q][key] = dO V^T     (A = Q / dO tile from LDS (KC image), B = K / V fragments in regs)
+//   dV^T += dO^T . P, dK^T += Q^T . dS            (A = transposed reads of the row-major Q / dO images, B = accumulators)
+// ============================================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+  constexpr int BQ = 32, NDS = D / 16, NDB = D / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qc = smem;                    // Q tile KC image [D/8][32][8]
+  char* Qr = smem + BQ * D * 2;       // Q tile row-major swizzled
+  char* Oc = smem + 2 * BQ * D * 2;   // dO tile KC
+  char* Or = smem + 3 * BQ * D * 2;   // dO tile row-major
+  float* rowc = (float*)(smem + 4 * BQ * D * 2);  // [2][32]: lse*log2e, delta
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
+  const int b = blockIdx.z, hkv = blockIdx.y;
+  const int G = a.Hq / a.Hkv;
+  const int k0 = blockIdx.x * 128 + w * 32;
+  const int ki = k0 + (l & 31);
+  const int shift = a.Skv - a.Sq;
+  const bf16* K = (const bf16*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const bf16* V = (const bf16*)a.v + b * a.v_sb + hkv * a.v_sh;
+  bf16x8 kf[NDS], vf[NDS];
+  {
+    const bf16* krow = ki < a.Skv ? K + (int64_t)ki * a.k_ss : nullptr;
+    const bf16* vrow = ki < a.Skv ? V + (int64_t)ki * a.v_ss : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+      kf[ds] = row_frag_global(krow, ds);
+      vf[ds] = row_frag_global(vrow, ds);
+    }
+  }
+  bool kvalid = ki < a.Skv;
+  if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + ki] != 0;
+  const float sc = a.scale * LOG2E;
+  f32x16 dk_acc[NDB], dv_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk_acc[i][r] = 0.f; dv_acc[i][r] = 0.f; }
+
+  // first query tile that can see any key of this workgroup
+  int qt0 = 0;
+  if (a.causal) qt0 = max(0, (int)blockIdx.x * 128 - shift) / BQ;
+  const int nqt = (a.Sq + BQ - 1) / BQ;
+  KcStage<D, BQ> qcs, ocs;  // NI = D/64 registers each; each tile is written to both images
+  for (int g = 0; g < G; ++g) {
+    const int hq = hkv * G + g;
+    const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
+    const bf16* dO = (const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * D;
+    const int64_t do_ss = (int64_t)a.Hq * D;
+    const float* lse = a.lse + ((int64_t)b * a.Hq + hq) * a.Sq;
+    const float* dlt = a.delta + ((int64_t)b * a.Hq + hq) * a.Sq;
+    for (int qt = qt0; qt < nqt; ++qt) {
+      const int qb = qt * BQ;
+      qcs.load(Q, a.q_ss, qb, a.Sq);
+      ocs.load(dO, do_ss, qb, a.Sq);
+      float rc = 0.f;
+      if (threadIdx.x < 64) {
+        const int qq = qb + (threadIdx.x & 31);
+        if (threadIdx.x < 32) rc = qq < a.Sq ? lse[qq] * LOG2E : INFINITY;
+        else rc = qq < a.Sq ? dlt[qq] : 0.f;
+      }
+      __syncthreads();  // previous tile fully consumed
+      qcs.store(Qc);
+      qcs.store_rowmajor(Qr);
+      ocs.store(Oc);
+      ocs.store_rowmajor(Or);
+      if (threadIdx.x < 64) rowc[threadIdx.x] = rc;
+      __syncthreads();
+      f32x16 s_acc, dp_acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) {
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BQ>(Qc, 0, ds), kf[ds], s_acc, 0, 0, 0);
+        dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BQ>(Oc, 0, ds), vf[ds], dp_acc, 0, 0, 0);
+      }
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = acc_row(r, h);
+        bool ok = kvalid;
+        if (a.causal) ok = ok && ki <= (qb + ql + shift);
+        const float p = ok ? exp2f(s_acc[r] * sc - rowc[ql]) : 0.f;
+        const float dsv = p * (dp_acc[r] - rowc[32 + ql]) * a.scale;
+        pf[r >> 3][r & 7] = (bf16)p;
+        dsf[r >> 3][r & 7] = (bf16)dsv;
+      }
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks_frag_t<D>(Or, db, s * 16), pf[s], dv_acc[db], 0, 0, 0);
+          dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks_frag_t<D>(Qr, db, s * 16), dsf[s], dk_acc[db], 0, 0, 0);
+        }
+    }
+  }
+  if (ki < a.Skv) {
+    bf16* dkrow = (bf16*)a.dk + b * a.k_sb + hkv * a.k_sh + (int64_t)ki * a.k_ss;
+    bf16* dvrow = (bf16*)a.dv + b * a.v_sb + hkv * a.v_sh + (int64_t)ki * a.v_ss;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 ok_, ov_;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ok_[e] = (bf16)dk_acc[db][rg * 4 + e];
+          ov_[e] = (bf16)dv_acc[db][rg * 4 + e];
+        }
+        *(bf16x4*)(dkrow + db * 32 + 8 * rg + 4 * h) = ok_;
+        *(bf16x4*)(dvrow + db * 32 + 8 * rg + 4 * h) = ov_;
+      }
+  }
+}
+
+// ============================================================================================================
+// fp32 parity kernels: one wave per (batch, head, query row); scores staged in LDS
+// ============================================================================================================
+__global__ __launch_bounds__(64) void attn_fwd_f32_kernel(AttnArgs a, int D) {
+  extern __shared__ float sm[];  // [Skv] scores, then [D] q
+  float* sc = sm;
+  float* qs = sm + a.Skv;
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, hkv = hq / (a.Hq / a.Hkv);
+  const int shift = a.Skv - a.Sq;
+  const float* Q = (const float*)a.q + b * a.q_sb + hq * a.q_sh + (int64_t)qi * a.q_ss;
+  const float* K = (const float*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const float* V = (const float*)a.v + b * a.v_sb + hkv * a.v_sh;
+  for (int d = lane; d < D; d += 64) qs[d] = Q[d];
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int k = lane; k < a.Skv; k += 64) {
+    bool ok = !(a.causal && k > qi + shift);
+    if (ok && a.kmask) ok = a.kmask[(int64_t)b * a.Skv + k] != 0;
+    float s = -INFINITY;
+    if (ok) {
+      s = 0.f;
+      const float* kr = K + (int64_t)k * a.k_ss;
+      for (int d = 0; d < D; ++d) s += qs[d] * kr[d];
+      s *= a.scale;
+    }
+    sc[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  const float ms = mx == -INFINITY ? 0.f : mx;
+  float sum = 0.f;
+  for (int k = lane; k < a.Skv; k += 64) {
+    const float p = expf(sc[k] - ms);
+    sc[k] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  float* o = (float*)a.out + (((int64_t)b * a.Sq + qi) * a.Hq + hq) * D;
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;
+    for (int k = 0; k < a.Skv; ++k) acc += sc[k] * V[(int64_t)k * a.v_ss + d];
+    o[d] = acc * inv;
+  }
+  if (lane == 0) a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] = sum > 0.f ? ms + logf(sum) : INFINITY;
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_f32_kernel(AttnArgs a, int D) {
+  extern __shared__ float sm[];  // [Skv] p, [Skv] ds, [D] q, [D] do
+  float* pp = sm;
+  float* dsb = sm + a.Skv;
+  float* qs = sm + 2 * a.Skv;
+  float* dos = qs + D;
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, hkv = hq / (a.Hq / a.Hkv);
+  const int shift = a.Skv - a.Sq;
+  const float* Q = (const float*)a.q + b * a.q_sb + hq * a.q_sh + (int64_t)qi * a.q_ss;
+  const float* K = (const float*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const float* V = (const float*)a.v + b * a.v_sb + hkv * a.v_sh;
+  const float* dO = (const float*)a.dout + (((int64_t)b * a.Sq + qi) * a.Hq + hq) * D;
+  const float lse = a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi];
+  const float dlt = a.delta[((int64_t)b * a.Hq + hq) * a.Sq + qi];
+  for (int d = lane; d < D; d += 64) { qs[d] = Q[d]; dos[d] = dO[d]; }
+  __syncthreads();
+  for (int k = lane; k < a.Skv; k += 64) {
+    bool ok = !(a.causal && k > qi + shift);
+    if (ok && a.kmask) ok = a.kmask[(int64_t)b * a.Skv + k] != 0;
+    float p = 0.f, dsv = 0.f;
+    if (ok) {
+      float s = 0.f, dp = 0.f;
+      const float* kr = K + (int64_t)k * a.k_ss;
+      const float* vr = V + (int64_t)k * a.v_ss;
+      for (int d = 0; d < D; ++d) { s += qs[d] * kr[d]; dp += dos[d] * vr[d]; }
+      p = expf(s * a.scale - lse);
+      dsv = p * (dp - dlt) * a.scale;
+    }
+    pp[k] = p;
+    dsb[k] = dsv;
+  }
+  __syncthreads();
+  float* dQ = (float*)a.dq + b * a.q_sb + hq * a.q_sh + (int64_t)qi * a.q_ss;
+  float* dK = (float*)a.dk + b * a.k_sb + hkv * a.k_sh;
+  float* dV = (float*)a.dv + b * a.v_sb + hkv * a.v_sh;
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;
+    const float qd = qs[d], dod = dos[d];
+    for (int k = 0; k < a.Skv; ++k) {
+      const float dsv = dsb[k];
+      if (dsv != 0.f || pp[k] != 0.f) {
+        acc += dsv * K[(int64_t)k * a.k_ss + d];
+        atomicAdd(dK + (int64_t)k * a.k_ss + d, dsv * qd);
+        atomicAdd(dV + (int64_t)k * a.v_ss + d, pp[k] * dod);
+      }
+    }
+    dQ[d] = acc;
+  }
+}
+
+template <int D>
+int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
+  const size_t lds = 2 * 64 * D * 2;
+  dim3 grid((a.Sq + 127) / 128, a.Hq, a.B), block(256);
+  hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, block, lds, s, a);
+  return MM_OK;
+}
+template <int D>
+int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
+  {
+    const size_t lds = 3 * 64 * D * 2;
+    dim3 grid((a.Sq + 127) / 128, a.Hq, a.B), block(256);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, block, lds, s, a);
+  }
+  {
+    const size_t lds = 4 * 32 * D * 2 + 64 * sizeof(float);
+    dim3 grid((a.Skv + 127) / 128, a.Hkv, a.B), block(256);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, grid, block, lds, s, a);
+  }
+  return MM_OK;
+}
+
+}  // namespace
+
+static int check_common(int dtype, int B, int Sq, int Skv, int Hq, int Hkv, int D) {
+  if (B < 0 || Sq < 0 || Skv < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || D <= 0) return MM_ERR_ARG;
+  if (dtype == MM_BF16 && D != 64 && D != 128) return MM_ERR_UNSUPPORTED;
+  if (dtype == MM_F32 && (D > 256 || Skv > 12000)) return MM_ERR_UNSUPPORTED;
+  if (dtype != MM_BF16 && dtype != MM_F32) return MM_ERR_UNSUPPORTED;
+  return MM_OK;
+}
+
+extern "C" int mm_attn_fwd(int dtype, const void* q, const void* k, const void* v, int B, int Sq, int Skv, int Hq, int Hkv, int D,
+                           int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
+                           int64_t v_sh, const int64_t* key_mask, int causal, float scale, void* out, float* lse, void* stream) {
+  int rc = check_common(dtype, B, Sq, Skv, Hq, Hkv, D);
+  if (rc) return rc;
+  if (!q || !k || !v || !out || !lse) return MM_ERR_ARG;
+  if (B == 0 || Sq == 0) return MM_OK;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.B = B; a.Sq = Sq; a.Skv = Skv; a.Hq = Hq; a.Hkv = Hkv;
+  a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh; a.v_sb = v_sb; a.v_ss = v_ss; a.v_sh = v_sh;
+  a.kmask = key_mask; a.causal = causal; a.scale = scale; a.out = out; a.lse = lse;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MM_BF16) {
+    if ((q_sb | q_ss | q_sh | k_sb | k_ss | k_sh | v_sb | v_ss | v_sh) & 7) return MM_ERR_ALIGN;
+    if (!mm_aligned16(q) || !mm_aligned16(k) || !mm_aligned16(v) || !mm_aligned16(out)) return MM_ERR_ALIGN;
+    rc = D == 128 ? launch_bf16_fwd<128>(a, s) : launch_bf16_fwd<64>(a, s);
+  } else {
+    const size_t lds = (size_t)(Skv + D) * sizeof(float);
+    hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(Sq, Hq, B), dim3(64), lds, s, a, D);
+  }
+  MM_CHECK_LAUNCH();
+  return rc;
+}
+
+extern "C" int mm_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                           int B, int Sq, int Skv, int Hq, int Hkv, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                           int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, const int64_t* key_mask, int causal,
+                           float scale, void* dq, void* dk, void* dv, float* delta, void* stream) {
+  int rc = check_common(dtype, B, Sq, Skv, Hq, Hkv, D);
+  if (rc) return rc;
+  if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !delta) return MM_ERR_ARG;
+  if (B == 0 || Sq == 0) return MM_OK;
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.B = B; a.Sq = Sq; a.Skv = Skv; a.Hq = Hq; a.Hkv = Hkv;
+  a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh; a.v_sb = v_sb; a.v_ss = v_ss; a.v_sh = v_sh;
+  a.kmask = key_mask; a.causal = causal; a.scale = scale; a.out = (void*)out; a.lse = (float*)lse;
+  a.dout = dout; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * Sq * Hq;
+  if (dtype == MM_BF16) {
+    if ((q_sb | q_ss | q_sh | k_sb | k_ss | k_sh | v_sb | v_ss | v_sh) & 7) return MM_ERR_ALIGN;
+    hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, B, Sq, Hq, D, delta);
+    rc = D == 128 ? launch_bf16_bwd<128>(a, s) : launch_bf16_bwd<64>(a, s);
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const float*)out, (const float*)dout, B, Sq, Hq, D, delta);
+    const size_t lds = (size_t)(2 * Skv + 2 * D) * sizeof(float);
+    hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(Sq, Hq, B), dim3(64), lds, s, a, D);
+  }
+  MM_CHECK_LAUNCH();
+  return rc;
+}

@@ -1,0 +1,44 @@
+// Diagnostics: expose raw MFMA / transposed-LDS-read lane maps so the host-side tests can pin the fragment
+// layouts the GEMM and attention kernels rely on (guide: "check the map with exact integer data").
+#include "mm_common.h"
+
+namespace {
+__global__ void dbg_tr_read_kernel(const bf16* img, const int* byte_addr, bf16* out) {
+  __shared__ __attribute__((aligned(16))) bf16 lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = img[i];
+  __syncthreads();
+  bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, (char*)lds + byte_addr[threadIdx.x]));
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+__global__ void dbg_mfma32_kernel(const bf16* a, const bf16* b, float* out) {
+  bf16x8 fa = *(const bf16x8*)(a + threadIdx.x * 8), fb = *(const bf16x8*)(b + threadIdx.x * 8);
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) out[threadIdx.x * 16 + r] = acc[r];
+}
+__global__ void dbg_mfma16_kernel(const bf16* a, const bf16* b, float* out) {
+  bf16x8 fa = *(const bf16x8*)(a + threadIdx.x * 8), fb = *(const bf16x8*)(b + threadIdx.x * 8);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[threadIdx.x * 4 + r] = acc[r];
+}
+}  // namespace
+
+extern "C" int mm_debug_tr_read(const void* img_bf16_4096, const void* lane_byte_addr_i32_64, void* out_bf16_256, void* stream) {
+  if (!img_bf16_4096 || !lane_byte_addr_i32_64 || !out_bf16_256) return MM_ERR_ARG;
+  hipLaunchKernelGGL(dbg_tr_read_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)img_bf16_4096, (const int*)lane_byte_addr_i32_64, (bf16*)out_bf16_256);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+extern "C" int mm_debug_mfma(int shape, const void* a_frag_bf16_512, const void* b_frag_bf16_512, void* out_f32, void* stream) {
+  if (!a_frag_bf16_512 || !b_frag_bf16_512 || !out_f32) return MM_ERR_ARG;
+  if (shape == 32)
+    hipLaunchKernelGGL(dbg_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)a_frag_bf16_512, (const bf16*)b_frag_bf16_512, (float*)out_f32);
+  else if (shape == 16)
+    hipLaunchKernelGGL(dbg_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)a_frag_bf16_512, (const bf16*)b_frag_bf16_512, (float*)out_f32);
+  else
+    return MM_ERR_ARG;
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}

@@ -1,0 +1,394 @@
+// GEMM for every linear layer on the path (forward, input-gradient, weight-gradient).
+//
+// bf16 path: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Operands are staged HBM -> registers -> LDS with
+// 16-byte accesses and one barrier per K-step (double-buffered LDS, next tile's global loads issued
+// before the current tile's MFMAs).  Two LDS images, chosen per operand by how it lies in memory:
+//   KC (K contiguous, global [X][K])  image [k/8][x][8]      fragments by ds_read_b128 (conflict free)
+//   KS (K strided,    global [K][X])  image [k][x] swizzled  fragments by 2x ds_read_b64_tr_b16
+// so NT / NN / TN need no transposed copy of any tensor.  The MFMA is issued with swapped operands
+// (D^T = B^T A^T) so each lane owns 4 consecutive output columns -> 8-byte stores, and bias /
+// activation / residual / accumulate are applied in registers.
+// Out-of-range rows are handled by buffer loads (hardware bounds check returns 0), so M, N need no
+// padding and K only has to be a multiple of 8 for K-contiguous operands.
+// Workgroup ids are remapped XCD-aware (bijective) and grouped along M so one XCD's L2 holds the
+// A/B panels its concurrent workgroups share.
+//
+// f32 path (parity only): 64x64x16 tiles on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+#include "mm_common.h"
+
+namespace {
+
+struct GemmArgs {
+  int M, N, K;
+  const void* A; int lda;
+  const void* B; int ldb;
+  void* C; int ldc;
+  const void* bias;
+  const void* residual; int ldr;
+  int epi;
+  int nbm, nbn;
+};
+
+__device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+__device__ __forceinline__ void block_to_tile(int bid, int nbm, int nbn, int& pm, int& pn) {
+  const int nwg = nbm * nbn;
+  // bijective XCD remap: blocks b and b+8 share an XCD; give each XCD a contiguous chunk of tile ids
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  constexpr int GROUP_M = 8;
+  const int group = GROUP_M * nbn;
+  const int gid = swz / group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = min(nbm - first_m, GROUP_M);
+  const int in_g = swz - gid * group;
+  pm = first_m + in_g % gsz;
+  pn = in_g / gsz;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
+  if (bytes < 0) bytes = 0;
+  const unsigned nb = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nb, 0x00020000);
+}
+
+__device__ __forceinline__ int ks_swz(int k) { return (k & 3) | ((k >> 1) & 4); }
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+// ---- staging: global -> registers ------------------------------------------------------------------
+// KC operand: rows x0.., tile [128 x][64 k]; lane: r_in = l&7, kc = l>>3; wave w, i: row = (w*4+i)*8 + r_in
+template <bool KC>
+__device__ __forceinline__ void stage_load(u32x4 (&r)[4], const bf16* base, int ld, int x0, int Xtot, int k0, int Ktot) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if constexpr (KC) {
+    const bf16* b = base + (int64_t)x0 * ld + k0;
+    auto rs = make_rsrc(b, ((int64_t)(Xtot - x0) * ld - k0) * 2);
+    const int r_in = l & 7, kc = l >> 3;
+    const bool kok = (k0 + kc * 8) < Ktot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (w * 4 + i) * 8 + r_in;
+      unsigned off = (unsigned)(row * ld + kc * 8) * 2u;
+      if (!kok) off = 0xFFFFFFFFu;
+      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    }
+  } else {
+    const bf16* b = base + (int64_t)k0 * ld + x0;
+    auto rs = make_rsrc(b, ((int64_t)(Ktot - k0) * ld - x0) * 2);
+    const int xc = l & 15, kr = l >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = i * 16 + w * 4 + kr;
+      unsigned off = (unsigned)(k * ld + xc * 8) * 2u;
+      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void stage_store(const u32x4 (&r)[4], char* tile) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if constexpr (KC) {
+    const int r_in = l & 7, kc = l >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (w * 4 + i) * 8 + r_in;
+      *(u32x4*)(tile + (kc * 128 + row) * 16) = r[i];
+    }
+  } else {
+    const int xc = l & 15, kr = l >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = i * 16 + w * 4 + kr;
+      *(u32x4*)(tile + k * 256 + (((xc >> 1) ^ ks_swz(k)) * 32) + (xc & 1) * 16) = r[i];
+    }
+  }
+}
+
+// ---- fragments: LDS -> registers ---------------------------------------------------------------------
+// returns the 16x32 MFMA operand fragment (lane: idx = l&15 along x, k = 8*(l>>4)+j) for x-block xb (16 wide)
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
+  const int l = threadIdx.x & 63;
+  if constexpr (KC) {
+    return *(const bf16x8*)(tile + ((ks * 4 + (l >> 4)) * 128 + xb * 16 + (l & 15)) * 16);
+  } else {
+    const int g = l >> 4, i = l & 15, q = i >> 2, p = i & 3;
+    const int k = ks * 32 + 8 * g + q;
+    const int sw = (xb ^ ks_swz(k)) * 32 + p * 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + k * 256 + sw));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + (k + 4) * 256 + sw));
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
+  int pm, pn;
+  block_to_tile(blockIdx.x, g.nbm, g.nbn, pm, pn);
+  const int m0 = pm * BM, n0 = pn * BN;
+  const bf16* A = (const bf16*)g.A;
+  const bf16* B = (const bf16*)g.B;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[4], rb[4];
+  const int nk = (g.K + BK - 1) / BK;
+  stage_load<A_KC>(ra, A, g.lda, m0, g.M, 0, g.K);
+  stage_load<B_KC>(rb, B, g.ldb, n0, g.N, 0, g.K);
+  stage_store<A_KC>(ra, smem);
+  stage_store<B_KC>(rb, smem + TILE_BYTES);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * (2 * TILE_BYTES);
+    char* nxt = smem + ((kt + 1) & 1) * (2 * TILE_BYTES);
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      stage_load<A_KC>(ra, A, g.lda, m0, g.M, (kt + 1) * BK, g.K);
+      stage_load<B_KC>(rb, B, g.ldb, n0, g.N, (kt + 1) * BK, g.K);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag_load<A_KC>(cur, wm * 4 + i, ks);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag_load<B_KC>(cur + TILE_BYTES, wn * 4 + j, ks);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      stage_store<A_KC>(ra, nxt);
+      stage_store<B_KC>(rb, nxt + TILE_BYTES);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + (l&15)][n0 + wn*64 + j*16 + 4*(l>>4) + r]
+  bf16* C = (bf16*)g.C;
+  const bf16* bias = (const bf16*)g.bias;
+  const bf16* R = (const bf16*)g.residual;
+  const int epi = g.epi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (l & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (l >> 4);
+      if (n >= g.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const bool full = (n + 3) < g.N;
+      bf16* cp = C + (int64_t)m * g.ldc + n;
+      if (epi & MM_EPI_BIAS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (full || n + r < g.N) v[r] += (float)bias[n + r];
+      }
+      if (epi & MM_EPI_GELU_ERF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_gelu_erf(v[r]);
+      } else if (epi & MM_EPI_QUICK_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_quick_gelu(v[r]);
+      }
+      if (epi & MM_EPI_RESIDUAL) {
+        const bf16* rp = R + (int64_t)m * g.ldr + n;
+        if (full) {
+          bf16x4 rv = *(const bf16x4*)rp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < g.N) v[r] += (float)rp[r];
+        }
+      }
+      if (epi & MM_EPI_ACCUMULATE) {
+        if (full) {
+          bf16x4 cv = *(const bf16x4*)cp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)cv[r];
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < g.N) v[r] += (float)cp[r];
+        }
+      }
+      if (full) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+        *(bf16x4*)cp = o;
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < g.N) cp[r] = (bf16)v[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// exact-fp32 GEMM (parity path).  64x64 tile, BK = 16, 4 waves each 32x32 (2x2 of 16x16x4 f32 MFMA).
+// LDS images are [k][x] for both operands (any global layout is re-tiled by scalar loads).
+// ------------------------------------------------------------------------------------------------------
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int TM = 64, TN = 64, TK = 16, LD = 80;  // LD = 80: rows k, k+1 land on disjoint bank halves
+  __shared__ float As[TK * LD];
+  __shared__ float Bs[TK * LD];
+  const int pm = blockIdx.x % g.nbm, pn = blockIdx.x / g.nbm;
+  const int m0 = pm * TM, n0 = pn * TN;
+  const float* A = (const float*)g.A;
+  const float* B = (const float*)g.B;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  f32x4 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < g.K; k0 += TK) {
+    // each thread loads 4 elements of A-tile and 4 of B-tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = threadIdx.x + e * 256;  // 0..1023 over [TK][64]
+      int k, x;
+      // A: NT/NN are [M][K] (k fastest), TN is [K][M] (m fastest)
+      if (LAYOUT == MM_GEMM_TN) { x = idx & 63; k = idx >> 6; } else { k = idx & 15; x = idx >> 4; }
+      float va = 0.f;
+      if (m0 + x < g.M && k0 + k < g.K)
+        va = (LAYOUT == MM_GEMM_TN) ? A[(int64_t)(k0 + k) * g.lda + m0 + x] : A[(int64_t)(m0 + x) * g.lda + k0 + k];
+      As[k * LD + x] = va;
+      // B: NT is [N][K] (k fastest), NN/TN are [K][N] (n fastest)
+      if (LAYOUT == MM_GEMM_NT) { k = idx & 15; x = idx >> 4; } else { x = idx & 63; k = idx >> 6; }
+      float vb = 0.f;
+      if (n0 + x < g.N && k0 + k < g.K)
+        vb = (LAYOUT == MM_GEMM_NT) ? B[(int64_t)(n0 + x) * g.ldb + k0 + k] : B[(int64_t)(k0 + k) * g.ldb + n0 + x];
+      Bs[k * LD + x] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; kk += 4) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = As[(kk + (l >> 4)) * LD + wm * 32 + i * 16 + (l & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = Bs[(kk + (l >> 4)) * LD + wn * 32 + j * 16 + (l & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j], fa[i], acc[i][j], 0, 0, 0);  // swapped: D^T
+    }
+    __syncthreads();
+  }
+  float* C = (float*)g.C;
+  const float* bias = (const float*)g.bias;
+  const float* R = (const float*)g.residual;
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 32 + i * 16 + (l & 15);
+    if (m >= g.M) continue;
+    for (int j = 0; j < 2; ++j) {
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 32 + j * 16 + 4 * (l >> 4) + r;
+        if (n >= g.N) continue;
+        float v = acc[i][j][r];
+        if (g.epi & MM_EPI_BIAS) v += bias[n];
+        if (g.epi & MM_EPI_GELU_ERF) v = act_gelu_erf(v);
+        else if (g.epi & MM_EPI_QUICK_GELU) v = act_quick_gelu(v);
+        if (g.epi & MM_EPI_RESIDUAL) v += R[(int64_t)m * g.ldr + n];
+        float* cp = C + (int64_t)m * g.ldc + n;
+        if (g.epi & MM_EPI_ACCUMULATE) v += *cp;
+        *cp = v;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void colsum_kernel(const T* X, int M, int N, int ldx, T* out, int accumulate) {
+  // one block per 64 columns; 4 waves split the rows; lane = column
+  __shared__ float red[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  float s = 0.f;
+  if (n < N)
+    for (int m = w; m < M; m += 4) s += to_f32(X[(int64_t)m * ldx + n]);
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && n < N) {
+    float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (accumulate) t += to_f32(out[n]);
+    out[n] = from_f32<T>(t);
+  }
+}
+
+}  // namespace
+
+extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                       int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;
+  if (M == 0 || N == 0) return MM_OK;
+  if (!A || !B || !C) return MM_ERR_ARG;
+  if ((epilogue & MM_EPI_BIAS) && !bias) return MM_ERR_ARG;
+  if ((epilogue & MM_EPI_RESIDUAL) && !residual) return MM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, 0, 0};
+  if (dtype == MM_BF16) {
+    if ((lda & 7) || (ldb & 7) || (ldc & 3) || ((epilogue & MM_EPI_RESIDUAL) && (ldr & 3))) return MM_ERR_ALIGN;
+    if (!mm_aligned16(A) || !mm_aligned16(B) || (((uintptr_t)C) & 7)) return MM_ERR_ALIGN;
+    g.nbm = (M + BM - 1) / BM;
+    g.nbn = (N + BN - 1) / BN;
+    const int64_t nwg = (int64_t)g.nbm * g.nbn;
+    if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+    const size_t lds = 4 * TILE_BYTES;
+    dim3 grid((unsigned)nwg), block(256);
+    switch (layout) {
+      case MM_GEMM_NT: hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, g); break;
+      case MM_GEMM_NN: hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, g); break;
+      default: hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, g); break;
+    }
+  } else if (dtype == MM_F32) {
+    g.nbm = (M + 63) / 64;
+    g.nbn = (N + 63) / 64;
+    dim3 grid((unsigned)(g.nbm * g.nbn)), block(256);
+    switch (layout) {
+      case MM_GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<MM_GEMM_NT>), grid, block, 0, s, g); break;
+      case MM_GEMM_NN: hipLaunchKernelGGL((gemm_f32_kernel<MM_GEMM_NN>), grid, block, 0, s, g); break;
+      default: hipLaunchKernelGGL((gemm_f32_kernel<MM_GEMM_TN>), grid, block, 0, s, g); break;
+    }
+  } else {
+    return MM_ERR_UNSUPPORTED;
+  }
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_colsum(int dtype, const void* X, int M, int N, int ldx, void* out, int accumulate, void* stream) {
+  if (!X || !out || M < 0 || N <= 0) return MM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((N + 63) / 64), block(256);
+  if (dtype == MM_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, s, (const bf16*)X, M, N, ldx, (bf16*)out, accumulate);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)X, M, N, ldx, (float*)out, accumulate);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}

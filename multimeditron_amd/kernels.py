@@ -1,0 +1,328 @@
+"""Tensor-level wrappers over the C ABI (include/mm_hip.h).  torch is used for device memory and the current
+HIP stream only; every arithmetic step below is a libmmhip kernel.  No autograd here (see functional.py)."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_ACCUMULATE, EPI_BIAS, EPI_GELU_ERF, EPI_QUICK_GELU, EPI_RESIDUAL, GEMM_NN, GEMM_NT, GEMM_TN,
+                   MM_BF16, MM_F32, call)
+
+_DT = {torch.bfloat16: MM_BF16, torch.float32: MM_F32}
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"libmmhip supports bf16/f32 tensors, got {t.dtype}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.MMHipError("libmmhip kernels need device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = 0,
+         accumulate: bool = False, ldc_pad: bool = False) -> torch.Tensor:
+    """Raw GEMM on 2-D row-major tensors (strides taken from .stride(0)).  Returns C [M, N] (a view of a padded
+    buffer when ldc_pad)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        if ldc_pad:
+            ld = (N + 63) // 64 * 64
+            buf = torch.empty((M, ld), dtype=a.dtype, device=a.device)
+            out = buf[:, :N]
+        else:
+            out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    assert out.stride(1) == 1
+    epi = act
+    if bias is not None:
+        epi |= EPI_BIAS
+    if residual is not None:
+        epi |= EPI_RESIDUAL
+        assert residual.stride(-1) == 1
+    if accumulate:
+        epi |= EPI_ACCUMULATE
+    call("mm_gemm", dt(a), layout, M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(bias),
+         _p(residual), residual.stride(0) if residual is not None else 0, epi, _stream())
+    return out
+
+
+def linear_fwd(x2d, w, bias=None, residual=None, act=0, ldc_pad=False):
+    """y[M,N] = x[M,K] @ w[N,K]^T (+bias)(act)(+residual)."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    return gemm(GEMM_NT, x2d, w, M, N, K, bias=bias, residual=residual, act=act, ldc_pad=ldc_pad)
+
+
+def linear_dgrad(dy2d, w, out=None):
+    """dx[M,K] = dy[M,N] @ w[N,K]."""
+    M = dy2d.shape[0]
+    N, K = w.shape
+    return gemm(GEMM_NN, dy2d, w, M, K, N, out=out)
+
+
+def linear_wgrad(dy2d, x2d, out, accumulate):
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    return gemm(GEMM_TN, dy2d, x2d, N, K, M, out=out, accumulate=accumulate)
+
+
+def colsum(x2d, out, accumulate):
+    call("mm_colsum", dt(x2d), _p(x2d), x2d.shape[0], x2d.shape[1], x2d.stride(0), _p(out), int(accumulate), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ splice
+def splice_build_map(batch_idx, token_range, S, T):
+    m = torch.empty(T, dtype=torch.int32, device=batch_idx.device if batch_idx is not None else "cuda")
+    n = 0 if batch_idx is None else batch_idx.numel()
+    call("mm_splice_build_map", _p(batch_idx) if n else None, _p(token_range) if n else None, n, S, T, _p(m), _stream())
+    return m
+
+
+def embed_splice_fwd(emb, ids, proj, src_map):
+    T = ids.numel()
+    H = emb.shape[1]
+    out = torch.empty((T, H), dtype=emb.dtype, device=emb.device)
+    call("mm_embed_splice_fwd", dt(emb), _p(emb), emb.shape[0], H, _p(ids), _p(proj), _p(src_map) if proj is not None else None, T,
+         _p(out), _stream())
+    return out
+
+
+def embed_splice_bwd(dE, ids, src_map, batch_idx, token_range, S, dproj, demb):
+    T, H = dE.shape
+    n = 0 if batch_idx is None else batch_idx.numel()
+    call("mm_embed_splice_bwd", dt(dE), _p(dE), H, _p(ids), _p(src_map), T, _p(batch_idx) if n else None,
+         _p(token_range) if n else None, n, S, _p(dproj), _p(demb), demb.shape[0] if demb is not None else 0, _stream())
+
+
+# ------------------------------------------------------------------------------------------------ ViT glue
+def patchify(pixels, ps, kpad, dtype):
+    n, c, h, w = pixels.shape
+    assert c == 3 and pixels.dtype == torch.float32 and pixels.is_contiguous()
+    P = (h // ps) * (w // ps)
+    out = torch.empty((n * P, kpad), dtype=dtype, device=pixels.device)
+    call("mm_patchify", _DT[dtype], _p(pixels), n, h, w, ps, kpad, _p(out), _stream())
+    return out
+
+
+def vit_embed_fwd(patch_out, cls, pos, n, P):
+    D = cls.numel()
+    x = torch.empty((n, P + 1, D), dtype=patch_out.dtype, device=patch_out.device)
+    call("mm_vit_embed_fwd", dt(patch_out), _p(patch_out), _p(cls), _p(pos), n, P, D, _p(x), _stream())
+    return x
+
+
+def vit_embed_bwd(dx, dcls, dpos, accumulate, want_dpatch=True):
+    n, T, D = dx.shape
+    P = T - 1
+    dpatch = torch.empty((n * P, D), dtype=dx.dtype, device=dx.device) if want_dpatch else None
+    call("mm_vit_embed_bwd", dt(dx), _p(dx), n, P, D, _p(dpatch), _p(dcls), _p(dpos), int(accumulate), _stream())
+    return dpatch
+
+
+def drop_cls_fwd(x):
+    n, T, D = x.shape
+    out = torch.empty((n, T - 1, D), dtype=x.dtype, device=x.device)
+    call("mm_drop_cls_fwd", dt(x), _p(x), n, T - 1, D, _p(out), _stream())
+    return out
+
+
+def drop_cls_bwd(dy):
+    n, P, D = dy.shape
+    out = torch.empty((n, P + 1, D), dtype=dy.dtype, device=dy.device)
+    call("mm_drop_cls_bwd", dt(dy), _p(dy), n, P, D, _p(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def rmsnorm_fwd(x2d, w, eps):
+    M, H = x2d.shape
+    y = torch.empty_like(x2d)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    call("mm_rmsnorm_fwd", dt(x2d), _p(x2d), _p(w), M, H, float(eps), _p(y), _p(rstd), _stream())
+    return y, rstd
+
+
+def norm_bwd_blocks(M):
+    return _lib.lib().mm_norm_bwd_blocks(M)
+
+
+def rmsnorm_bwd(dy2d, x2d, w, rstd):
+    M, H = x2d.shape
+    dx = torch.empty_like(x2d)
+    dwp = torch.empty((norm_bwd_blocks(M), H), dtype=torch.float32, device=x2d.device)
+    call("mm_rmsnorm_bwd", dt(x2d), _p(dy2d), _p(x2d), _p(w), _p(rstd), M, H, _p(dx), _p(dwp), _stream())
+    return dx, dwp
+
+
+def layernorm_fwd(x2d, w, b, eps):
+    M, H = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    call("mm_layernorm_fwd", dt(x2d), _p(x2d), _p(w), _p(b), M, H, float(eps), _p(y), _p(mean), _p(rstd), _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, w, mean, rstd):
+    M, H = x2d.shape
+    dx = torch.empty_like(x2d)
+    nb = norm_bwd_blocks(M)
+    dwp = torch.empty((nb, H), dtype=torch.float32, device=x2d.device)
+    dbp = torch.empty((nb, H), dtype=torch.float32, device=x2d.device)
+    call("mm_layernorm_bwd", dt(x2d), _p(dy2d), _p(x2d), _p(w), _p(mean), _p(rstd), M, H, _p(dx), _p(dwp), _p(dbp), _stream())
+    return dx, dwp, dbp
+
+
+def reduce_partials(partial, out, accumulate):
+    call("mm_reduce_partials", dt(out), _p(partial), partial.shape[0], partial.shape[1], _p(out), int(accumulate), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ rope
+def rope_table(position_ids, inv_freq, round_bf16):
+    T = position_ids.numel()
+    half = inv_freq.numel()
+    cos = torch.empty((T, half), dtype=torch.float32, device=position_ids.device)
+    sin = torch.empty_like(cos)
+    call("mm_rope_table", _p(position_ids), _p(inv_freq), T, half, int(round_bf16), _p(cos), _p(sin), _stream())
+    return cos, sin
+
+
+def rope_apply_(x, T, nheads, D, ld, cos, sin, inverse=False):
+    """in place on x (any tensor whose storage at data_ptr is [T, nheads, D] with row stride ld)."""
+    call("mm_rope_apply", dt(x), _p(x), T, nheads, D, ld, _p(cos), _p(sin), int(inverse), _stream())
+    return x
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _strides3(t):  # t: [B, S, H, D] view
+    assert t.dim() == 4 and t.stride(3) == 1
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def attn_fwd(q, k, v, key_mask, causal, scale):
+    """q [B,Sq,Hq,D], k/v [B,Skv,Hkv,D] (strided views ok) -> out [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] f32."""
+    B, Sq, Hq, D = q.shape
+    Skv, Hkv = k.shape[1], k.shape[2]
+    out = torch.empty((B, Sq, Hq, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
+    call("mm_attn_fwd", dt(q), _p(q), _p(k), _p(v), B, Sq, Skv, Hq, Hkv, D, *_strides3(q), *_strides3(k), *_strides3(v),
+         _p(key_mask), int(causal), float(scale), _p(out), _p(lse), _stream())
+    return out, lse
+
+
+def attn_bwd(q, k, v, out, dout, lse, key_mask, causal, scale, dq, dk, dv):
+    """dq/dk/dv: preallocated views with the SAME strides as q/k/v."""
+    B, Sq, Hq, D = q.shape
+    Skv, Hkv = k.shape[1], k.shape[2]
+    assert _strides3(dq) == _strides3(q) and _strides3(dk) == _strides3(k) and _strides3(dv) == _strides3(v)
+    assert dout.is_contiguous() and out.is_contiguous()
+    delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
+    call("mm_attn_bwd", dt(q), _p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), B, Sq, Skv, Hq, Hkv, D, *_strides3(q),
+         *_strides3(k), *_strides3(v), _p(key_mask), int(causal), float(scale), _p(dq), _p(dk), _p(dv), _p(delta), _stream())
+
+
+# ------------------------------------------------------------------------------------------------ activations
+def swiglu_fwd(gu, I):
+    M = gu.shape[0]
+    out = torch.empty((M, I), dtype=gu.dtype, device=gu.device)
+    call("mm_swiglu_fwd", dt(gu), _p(gu), M, I, _p(out), _stream())
+    return out
+
+
+def swiglu_bwd(gu, dout, I):
+    dgu = torch.empty_like(gu)
+    call("mm_swiglu_bwd", dt(gu), _p(gu), _p(dout), gu.shape[0], I, _p(dgu), _stream())
+    return dgu
+
+
+def gelu_fwd(x, kind):
+    y = torch.empty_like(x)
+    call("mm_gelu_fwd", dt(x), kind, _p(x), x.numel(), _p(y), _stream())
+    return y
+
+
+def gelu_bwd(x, dy, kind):
+    dx = torch.empty_like(x)
+    call("mm_gelu_bwd", dt(x), kind, _p(x), _p(dy), x.numel(), _p(dx), _stream())
+    return dx
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    call("mm_add", dt(a), _p(a), _p(b), a.numel(), _p(y), _stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ loss
+def ce_fwd(logits2d, V, labels):
+    """logits2d: [T, ld] view with V valid columns.  -> (loss_and_count [2] f32, lse [T])."""
+    T = logits2d.shape[0]
+    ld = logits2d.stride(0)
+    lse = torch.empty(T, dtype=torch.float32, device=logits2d.device)
+    loss_row = torch.empty(T, dtype=torch.float32, device=logits2d.device)
+    out = torch.empty(2, dtype=torch.float32, device=logits2d.device)
+    call("mm_ce_fwd", dt(logits2d), _p(logits2d), T, V, ld, _p(labels), _p(lse), _p(loss_row), _stream())
+    call("mm_ce_reduce", _p(loss_row), _p(labels), T, _p(out), _stream())
+    return out, lse
+
+
+def ce_bwd(logits2d, V, labels, lse, loss_and_count, gscale, dlogits2d):
+    T = logits2d.shape[0]
+    ld = logits2d.stride(0)
+    assert dlogits2d.stride(0) == ld
+    call("mm_ce_bwd", dt(logits2d), _p(logits2d), T, V, ld, _p(labels), _p(lse), _p(loss_and_count), _p(gscale), _p(dlogits2d),
+         _stream())
+    return dlogits2d
+
+
+def argmax_softmax(logits2d, V, temperature):
+    rows = logits2d.shape[0]
+    out = torch.empty(rows, dtype=torch.int64, device=logits2d.device)
+    call("mm_argmax_softmax", dt(logits2d), _p(logits2d), rows, V, logits2d.stride(0), float(temperature), _p(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def gradnorm(flat_grads, max_norm):
+    """flat_grads: list of 1-D flat gradient buffers -> device tensor [2] = (total_norm, clip_coef)."""
+    nblk = 1024
+    dev = flat_grads[0].device
+    partial = torch.empty(nblk * len(flat_grads), dtype=torch.float32, device=dev)
+    for i, g in enumerate(flat_grads):
+        call("mm_gradnorm_partial", dt(g), _p(g), g.numel(), partial.data_ptr() + 4 * nblk * i, nblk, _stream())
+    total = torch.empty(2, dtype=torch.float32, device=dev)
+    call("mm_gradnorm_finish", _p(partial), nblk * len(flat_grads), float(max_norm), _p(total), _stream())
+    return total
+
+
+def adamw_step(p, g, master, m, v, lr, beta1, beta2, eps, wd, step, clip=None):
+    call("mm_adamw_step", dt(p), _p(p), _p(g), _p(master), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), float(wd), int(step), _p(clip), _stream())
+
+
+def cast(src, dtype):
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    call("mm_cast", dt(src), _DT[dtype], _p(src), _p(dst), src.numel(), _stream())
+    return dst

@@ -1,0 +1,441 @@
+"""Kernel-level parity (GPU): every libmmhip entry point, called through the C ABI (ctypes), against a plain
+PyTorch fp32 computation of the same op on the same seeded inputs.
+
+Tolerances: MM_F32 kernels 2e-5 rel-L2 (exact-fp32 MFMA / VALU, different summation order);
+MM_BF16 kernels 1e-2 rel-L2 vs the fp32 result computed from the SAME bf16-rounded inputs (bf16 output rounding
+is 2^-9 relative per element; typical measured values are 2e-3..4e-3)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from multimeditron_amd import kernels
+    return kernels
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g) * scale
+    return x.to(dtype)
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1e-2}
+
+
+def test_lane_maps(K):
+    """Pins the hardware lane maps every MFMA kernel here assumes (exact small-integer data)."""
+    from multimeditron_amd._lib import call
+    g = torch.Generator().manual_seed(0)
+    # --- MFMA 32x32x16: A[i][k]: lane l holds A[l&31][8*(l>>5)+j]; B[k][n]: lane holds B[8*(l>>5)+j][l&31]
+    A = torch.randint(-4, 5, (32, 16), generator=g).float()
+    B = torch.randint(-4, 5, (16, 32), generator=g).float()
+    fa = torch.empty(64, 8)
+    fb = torch.empty(64, 8)
+    for l in range(64):
+        for j in range(8):
+            fa[l, j] = A[l & 31, 8 * (l >> 5) + j]
+            fb[l, j] = B[8 * (l >> 5) + j, l & 31]
+    out = torch.empty(64, 16, device="cuda")
+    call("mm_debug_mfma", 32, fa.bfloat16().cuda().data_ptr(), fb.bfloat16().cuda().data_ptr(), out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    C = A @ B
+    got = torch.empty(32, 32)
+    o = out.cpu()
+    for l in range(64):
+        for r in range(16):
+            got[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31] = o[l, r]
+    assert torch.equal(got, C), "32x32x16 C/D or A/B lane map"
+    # --- MFMA 16x16x32
+    A = torch.randint(-4, 5, (16, 32), generator=g).float()
+    B = torch.randint(-4, 5, (32, 16), generator=g).float()
+    for l in range(64):
+        for j in range(8):
+            fa[l, j] = A[l & 15, 8 * (l >> 4) + j]
+            fb[l, j] = B[8 * (l >> 4) + j, l & 15]
+    out = torch.empty(64, 4, device="cuda")
+    call("mm_debug_mfma", 16, fa.bfloat16().cuda().data_ptr(), fb.bfloat16().cuda().data_ptr(), out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    C = A @ B
+    got = torch.empty(16, 16)
+    o = out.cpu()
+    for l in range(64):
+        for r in range(4):
+            got[4 * (l >> 4) + r, l & 15] = o[l, r]
+    assert torch.equal(got, C), "16x16x32 C/D or A/B lane map"
+    # --- ds_read_b64_tr_b16: image [64 rows][64 cols] bf16 (128-B rows); each 16-lane group reads a 4x16 block
+    img = torch.arange(4096).reshape(64, 64) % 509
+    addr = torch.empty(64, dtype=torch.int32)
+    r0 = [0, 8, 20, 36]   # block first row per group
+    c0 = [0, 16, 32, 48]  # block first column per group
+    for l in range(64):
+        grp, i = l >> 4, l & 15
+        q, p = i >> 2, i & 3
+        addr[l] = ((r0[grp] + q) * 64 + c0[grp] + 4 * p) * 2
+    out = torch.empty(256, dtype=torch.bfloat16, device="cuda")
+    call("mm_debug_tr_read", img.bfloat16().cuda().data_ptr(), addr.cuda().data_ptr(), out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    o = out.float().cpu().reshape(64, 4)
+    for l in range(64):
+        grp, i = l >> 4, l & 15
+        for j in range(4):   # lane i receives column i of the block, row j in element j
+            assert o[l, j] == float(img[r0[grp] + j, c0[grp] + i]), f"tr read lane {l} elem {j}: {o[l].tolist()}"
+
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1028, 1024, 640), (64, 130, 64), (129, 72, 1088),
+               (2048, 512, 2048)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_gemm_layouts(K, dtype, layout, shape):
+    M, N, Kd = shape
+    a = rnd((M, Kd), dtype, 1)
+    b = rnd((N, Kd), dtype, 2)
+    ref = a.float() @ b.float().t()
+    if layout == "NT":
+        A, B, lay = a, b, 0
+    elif layout == "NN":
+        A, B, lay = a, b.t().contiguous(), 1
+        if N % 8:  # ldb must be a multiple of 8: pad the row stride
+            Bp = torch.zeros(Kd, (N + 7) // 8 * 8, dtype=dtype)
+            Bp[:, :N] = B
+            B = Bp
+    else:
+        A, B, lay = a.t().contiguous(), b.t().contiguous(), 2
+        if M % 8:
+            Ap = torch.zeros(Kd, (M + 7) // 8 * 8, dtype=dtype)
+            Ap[:, :M] = A
+            A = Ap
+        if N % 8:
+            Bp = torch.zeros(Kd, (N + 7) // 8 * 8, dtype=dtype)
+            Bp[:, :N] = B
+            B = Bp
+    out = K.gemm(lay, A.cuda(), B.cuda(), M, N, Kd, ldc_pad=True)
+    torch.cuda.synchronize()
+    assert out.shape == (M, N)
+    assert rel(out.float(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_asymmetric_identity(K, dtype):
+    # A = I with an asymmetric B catches a transposed C write or a permuted fragment map
+    n = 128
+    eye = torch.eye(n, dtype=dtype)
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(dtype)
+    for lay, A, B, ref in [(0, eye, b, b.float().t()), (1, eye, b, b.float()), (2, eye, b, b.float())]:
+        out = K.gemm(lay, A.cuda(), B.cuda(), n, n, n)
+        assert torch.equal(out.float().cpu(), ref), f"layout {lay}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_epilogues(K, dtype):
+    M, N, Kd = 200, 136, 256
+    a, w = rnd((M, Kd), dtype, 3, 0.5), rnd((N, Kd), dtype, 4, 0.1)
+    bias, res = rnd((N,), dtype, 5), rnd((M, N), dtype, 6)
+    base = a.float() @ w.float().t()
+    cases = {
+        "bias": (dict(bias=bias.cuda()), base + bias.float()),
+        "bias_gelu": (dict(bias=bias.cuda(), act=2), F.gelu(base + bias.float())),
+        "bias_quick": (dict(bias=bias.cuda(), act=4), (base + bias.float()) * torch.sigmoid(1.702 * (base + bias.float()))),
+        "residual": (dict(residual=res.cuda()), base + res.float()),
+        "bias_residual": (dict(bias=bias.cuda(), residual=res.cuda()), base + bias.float() + res.float()),
+    }
+    for name, (kw, ref) in cases.items():
+        out = K.gemm(0, a.cuda(), w.cuda(), M, N, Kd, **kw)
+        assert rel(out.float(), ref) < TOL[dtype], name
+    c0 = rnd((M, N), dtype, 7)
+    out = K.gemm(0, a.cuda(), w.cuda(), M, N, Kd, out=c0.cuda().clone(), accumulate=True)
+    assert rel(out.float(), base + c0.float()) < TOL[dtype]
+    cs = torch.empty(N, dtype=dtype, device="cuda")
+    K.colsum(res.cuda(), cs, False)
+    assert rel(cs.float(), res.float().sum(0)) < TOL[dtype]
+
+
+def attn_ref(q, k, v, mask, causal, scale):
+    # q [B,Sq,Hq,D], k/v [B,Skv,Hkv,D] fp32
+    B, Sq, Hq, D = q.shape
+    Skv, Hkv = k.shape[1], k.shape[2]
+    rep = Hq // Hkv
+    qq = q.permute(0, 2, 1, 3)
+    kk = k.permute(0, 2, 1, 3).repeat_interleave(rep, dim=1)
+    vv = v.permute(0, 2, 1, 3).repeat_interleave(rep, dim=1)
+    s = qq @ kk.transpose(2, 3) * scale
+    allowed = torch.ones(B, 1, Sq, Skv, dtype=torch.bool)
+    if causal:
+        allowed = allowed & (torch.arange(Skv)[None, :] <= (torch.arange(Sq)[:, None] + (Skv - Sq)))[None, None]
+    if mask is not None:
+        allowed = allowed & mask[:, None, None, :].bool()
+    row_ok = allowed.any(-1, keepdim=True)   # rows with no visible key: output defined as 0
+    s = s.masked_fill(~allowed & row_ok, float("-inf"))
+    p = torch.softmax(s, dim=-1) * row_ok
+    return (p @ vv).permute(0, 2, 1, 3)
+
+
+ATTN_CASES = [
+    # B, Sq, Skv, Hq, Hkv, D, causal, masked
+    (2, 128, 128, 2, 1, 64, True, False),
+    (1, 257, 257, 4, 4, 64, False, False),
+    (2, 50, 50, 3, 3, 64, False, False),
+    (2, 200, 200, 4, 2, 128, True, True),
+    (1, 384, 384, 8, 2, 128, True, False),
+    (2, 1, 77, 4, 2, 64, True, True),
+    (1, 40, 104, 2, 1, 128, True, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_fwd_bwd(K, dtype, case):
+    B, Sq, Skv, Hq, Hkv, D, causal, masked = case
+    # fused qkv buffer like the decoder uses: [B, S, (Hq + 2 Hkv) * D] when Sq == Skv, else separate tensors
+    q = rnd((B, Sq, Hq, D), dtype, 11)
+    k = rnd((B, Skv, Hkv, D), dtype, 12)
+    v = rnd((B, Skv, Hkv, D), dtype, 13)
+    do = rnd((B, Sq, Hq, D), dtype, 14)
+    mask = None
+    if masked:
+        mask = torch.ones(B, Skv, dtype=torch.long)
+        mask[0, : Skv // 3] = 0          # left padding on sample 0
+        if B > 1:
+            mask[1, Skv - 5:] = 0        # right padding on sample 1
+    scale = D ** -0.5
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qf, kf, vf, mask, causal, scale)
+    ref.backward(do.float())
+    if Sq == Skv:
+        buf = torch.cat([q.reshape(B, Sq, -1), k.reshape(B, Skv, -1), v.reshape(B, Skv, -1)], dim=-1).cuda()
+        W = buf.shape[-1]
+        qv = buf[..., : Hq * D].view(B, Sq, Hq, D)
+        kv = buf[..., Hq * D:(Hq + Hkv) * D].view(B, Skv, Hkv, D)
+        vv = buf[..., (Hq + Hkv) * D:].view(B, Skv, Hkv, D)
+        dbuf = torch.full_like(buf, float("nan")) if dtype == torch.bfloat16 else torch.zeros_like(buf)
+        dq = dbuf[..., : Hq * D].view(B, Sq, Hq, D)
+        dk = dbuf[..., Hq * D:(Hq + Hkv) * D].view(B, Skv, Hkv, D)
+        dv = dbuf[..., (Hq + Hkv) * D:].view(B, Skv, Hkv, D)
+    else:
+        qv, kv, vv = q.cuda(), k.cuda(), v.cuda()
+        mk = torch.zeros_like if dtype == torch.float32 else (lambda t: torch.full_like(t, float("nan")))
+        dq, dk, dv = mk(qv), mk(kv), mk(vv)
+    mg = mask.cuda() if mask is not None else None
+    out, lse = K.attn_fwd(qv, kv, vv, mg, causal, scale)
+    torch.cuda.synchronize()
+    # rows whose keys are all masked are garbage in the reference too (HF uniform softmax); compare valid rows
+    valid = torch.ones(B, Sq, dtype=torch.bool)
+    if mask is not None and causal:
+        for b in range(B):
+            for i in range(Sq):
+                valid[b, i] = bool(mask[b, : i + (Skv - Sq) + 1].any())
+    tol = TOL[dtype]
+    assert rel(out.float().cpu()[valid], ref.detach()[valid]) < tol
+    assert torch.isfinite(out.float()).all()
+    K.attn_bwd(qv, kv, vv, out, do.cuda(), lse, mg, causal, scale, dq, dk, dv)
+    torch.cuda.synchronize()
+    gtol = tol * 2
+    assert rel(dq.float().cpu()[valid], qf.grad[valid]) < gtol, "dq"
+    assert rel(dk.float(), kf.grad) < gtol, "dk"
+    assert rel(dv.float(), vf.grad) < gtol, "dv"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("H", [128, 1024, 4096])
+def test_norms(K, dtype, H):
+    M = 77
+    x, w, b, dy = rnd((M, H), dtype, 21), 1 + 0.1 * rnd((H,), torch.float32, 22), rnd((H,), dtype, 23), rnd((M, H), dtype, 24)
+    w = w.to(dtype)
+    tol = TOL[dtype]
+    # RMSNorm
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    ref = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
+    ref.backward(dy.float())
+    y, rstd = K.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-5)
+    assert rel(y.float(), ref.detach()) < tol
+    dx, dwp = K.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstd)
+    dw = torch.empty(H, dtype=dtype, device="cuda")
+    K.reduce_partials(dwp, dw, False)
+    assert rel(dx.float(), xf.grad) < tol * 2
+    assert rel(dw.float(), wf.grad) < tol * 2
+    # LayerNorm
+    xf, wf, bf = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = F.layer_norm(xf, (H,), wf, bf, 1e-5)
+    ref.backward(dy.float())
+    y, mean, rstd = K.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), 1e-5)
+    assert rel(y.float(), ref.detach()) < tol
+    dx, dwp, dbp = K.layernorm_bwd(dy.cuda(), x.cuda(), w.cuda(), mean, rstd)
+    dw, db = torch.empty(H, dtype=dtype, device="cuda"), torch.empty(H, dtype=dtype, device="cuda")
+    K.reduce_partials(dwp, dw, False)
+    K.reduce_partials(dbp, db, False)
+    assert rel(dx.float(), xf.grad) < tol * 2
+    assert rel(dw.float(), wf.grad) < tol * 2
+    assert rel(db.float(), bf.grad) < tol * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("D", [64, 128])
+def test_rope(K, dtype, D):
+    B, S, Hq, Hkv = 2, 37, 4, 2
+    W = (Hq + 2 * Hkv) * D
+    qkv = rnd((B * S, W), dtype, 31)
+    pos = torch.stack([torch.arange(S), torch.clamp(torch.arange(S) - 5, min=0)]).reshape(-1)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    ang = pos[:, None].float() * inv[None]
+    cos, sin = ang.cos(), ang.sin()
+    cg, sg = K.rope_table(pos.cuda(), inv.cuda(), False)
+    assert rel(cg, cos) < 1e-5 and rel(sg, sin) < 1e-5
+
+    def ref_rot(x, inverse=False):  # x [T, h, D]
+        c = torch.cat([cos, cos], -1)[:, None]
+        s = torch.cat([sin, sin], -1)[:, None] * (-1 if inverse else 1)
+        half = D // 2
+        rh = torch.cat([-x[..., half:], x[..., :half]], -1)
+        return x * c + rh * s
+
+    g = qkv.cuda().clone()
+    K.rope_apply_(g, B * S, Hq + Hkv, D, W, cg, sg)   # q and k heads are adjacent in the fused buffer
+    ref = qkv.float().clone()
+    ref[:, : (Hq + Hkv) * D] = ref_rot(ref[:, : (Hq + Hkv) * D].view(B * S, Hq + Hkv, D)).reshape(B * S, -1)
+    assert rel(g.float(), ref) < TOL[dtype]
+    K.rope_apply_(g, B * S, Hq + Hkv, D, W, cg, sg, inverse=True)
+    assert rel(g.float(), qkv.float()) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_activations(K, dtype):
+    M, I = 33, 256
+    gu, dout = rnd((M, 2 * I), dtype, 41), rnd((M, I), dtype, 42)
+    guf = gu.float().requires_grad_(True)
+    ref = F.silu(guf[:, :I]) * guf[:, I:]
+    ref.backward(dout.float())
+    tol = TOL[dtype]
+    assert rel(K.swiglu_fwd(gu.cuda(), I).float(), ref.detach()) < tol
+    assert rel(K.swiglu_bwd(gu.cuda(), dout.cuda(), I).float(), guf.grad) < tol * 2
+    x, dy = rnd((1000 + 3,), dtype, 43, 2.0), rnd((1000 + 3,), dtype, 44)
+    for kind, fn in [(0, F.gelu), (1, lambda t: t * torch.sigmoid(1.702 * t))]:
+        xf = x.float().requires_grad_(True)
+        r = fn(xf)
+        r.backward(dy.float())
+        assert rel(K.gelu_fwd(x.cuda(), kind).float(), r.detach()) < tol
+        assert rel(K.gelu_bwd(x.cuda(), dy.cuda(), kind).float(), xf.grad) < tol * 2
+    assert rel(K.add(x.cuda(), dy.cuda()).float(), x.float() + dy.float()) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("V", [130, 1000, 128258])
+def test_cross_entropy(K, dtype, V):
+    T = 19
+    ld = (V + 63) // 64 * 64
+    logits = rnd((T, V), dtype, 51, 2.0)
+    labels = torch.randint(0, V, (T,), generator=torch.Generator().manual_seed(52))
+    labels[::4] = -100
+    lf = logits.float().requires_grad_(True)
+    ref = F.cross_entropy(lf, labels, ignore_index=-100)
+    ref.backward()
+    buf = torch.zeros(T, ld, dtype=dtype, device="cuda")
+    buf[:, :V] = logits.cuda()
+    lc, lse = K.ce_fwd(buf[:, :V], V, labels.cuda())
+    assert abs(float(lc[0]) - float(ref)) < 1e-4 * max(1, abs(float(ref)))
+    assert int(lc[1]) == int((labels >= 0).sum())
+    d = torch.full_like(buf, float("nan"))
+    K.ce_bwd(buf[:, :V], V, labels.cuda(), lse, lc, None, d[:, :V])
+    assert rel(d[:, :V].float(), lf.grad) < (2e-5 if dtype == torch.float32 else 1e-2)
+    assert torch.all(d[:, V:] == 0)
+    for T_ in (0.1, 0.7):
+        got = K.argmax_softmax(buf[:, :V], V, T_).cpu()
+        want = torch.argmax(torch.softmax(logits / T_, dim=-1), dim=-1)   # in the logits dtype, as model.py:607-621
+        assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_embed_splice(K, dtype):
+    B, S, H, V, P = 2, 24, 128, 50, 4
+    emb = rnd((V, H), dtype, 61)
+    ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(62))
+    proj = rnd((3 * P, H), dtype, 63)
+    bi = torch.tensor([0] * P + [1] * (2 * P))
+    tr = torch.tensor(list(range(3, 3 + P)) + list(range(1, 1 + P)) + list(range(10, 10 + P)))
+    e = F.embedding(ids, emb.float())
+    ref = e.clone()
+    ref[bi, tr] = proj.float()
+    m = K.splice_build_map(bi.cuda(), tr.cuda(), S, B * S)
+    out = K.embed_splice_fwd(emb.cuda(), ids.cuda().reshape(-1), proj.cuda(), m)
+    assert torch.equal(out.float().cpu(), ref.reshape(B * S, H))
+    out2 = K.embed_splice_fwd(emb.cuda(), ids.cuda().reshape(-1), None, None)
+    assert torch.equal(out2.float().cpu(), e.reshape(B * S, H))
+    # backward
+    dE = rnd((B * S, H), dtype, 64)
+    ef = emb.float().requires_grad_(True)
+    pf = proj.float().requires_grad_(True)
+    r = F.embedding(ids, ef).clone()
+    r[bi, tr] = pf
+    r.reshape(B * S, H).backward(dE.float())
+    dproj = torch.empty_like(proj, device="cuda")
+    demb = torch.zeros_like(emb, device="cuda")
+    K.embed_splice_bwd(dE.cuda(), ids.cuda().reshape(-1), m, bi.cuda(), tr.cuda(), S, dproj, demb)
+    assert torch.equal(dproj.float().cpu(), pf.grad)
+    assert rel(demb.float(), ef.grad) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_vit_glue(K, dtype):
+    n, ps, img, Dv = 3, 14, 56, 128
+    P = (img // ps) ** 2
+    pix = rnd((n, 3, img, img), torch.float32, 71)
+    w = rnd((Dv, 3, ps, ps), dtype, 72, 0.05)
+    ref = F.conv2d(pix.to(dtype).float(), w.float(), stride=ps).flatten(2).transpose(1, 2)   # [n,P,Dv]
+    kpad = (3 * ps * ps + 63) // 64 * 64
+    patches = K.patchify(pix.cuda(), ps, kpad, dtype)
+    wp = torch.zeros(Dv, kpad, dtype=dtype)
+    wp[:, : 3 * ps * ps] = w.reshape(Dv, -1)
+    po = K.linear_fwd(patches, wp.cuda())
+    assert rel(po.float(), ref.reshape(n * P, Dv)) < TOL[dtype]
+    cls, pos = rnd((Dv,), dtype, 73), rnd((P + 1, Dv), dtype, 74)
+    x = K.vit_embed_fwd(po, cls.cuda(), pos.cuda(), n, P)
+    refx = torch.cat([cls.float().expand(n, 1, Dv), po.float().cpu().view(n, P, Dv)], 1) + pos.float()
+    assert rel(x.float(), refx) < TOL[dtype]
+    d = K.drop_cls_fwd(x)
+    assert torch.equal(d.cpu(), x[:, 1:].cpu())
+    db = K.drop_cls_bwd(d)
+    assert torch.equal(db[:, 1:].cpu(), d.cpu()) and torch.all(db[:, 0] == 0)
+    dx = rnd((n, P + 1, Dv), dtype, 75).cuda()
+    dcls = torch.empty(Dv, dtype=dtype, device="cuda")
+    dpos = torch.empty(P + 1, Dv, dtype=dtype, device="cuda")
+    dpatch = K.vit_embed_bwd(dx, dcls, dpos, False)
+    assert torch.equal(dpatch.view(n, P, Dv).cpu(), dx[:, 1:].cpu())
+    assert rel(dcls.float(), dx.float().cpu()[:, 0].sum(0)) < TOL[dtype]
+    assert rel(dpos.float(), dx.float().cpu().sum(0)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_adamw_and_gradnorm(K, dtype):
+    n = 100003
+    p32 = rnd((n,), torch.float32, 81)
+    g = rnd((n,), dtype, 82, 0.1)
+    p = p32.to(dtype)
+    master = p.float().cuda()
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    pg = p.cuda()
+    total = K.gradnorm([g.cuda()], 1.0)
+    nrm = float(g.float().norm())
+    assert abs(float(total[0]) - nrm) < 1e-3 * nrm
+    coef = min(1.0, 1.0 / (nrm + 1e-6))
+    ref_p = torch.nn.Parameter(p.float().clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    for step in (1, 2, 3):
+        ref_p.grad = g.float() * coef
+        opt.step()
+        K.adamw_step(pg, g.cuda(), master, m, v, 1e-2, 0.9, 0.95, 1e-8, 0.01, step, clip=total)
+    assert rel(master, ref_p.detach()) < 1e-5
+    assert rel(pg.float(), ref_p.detach()) < (1e-5 if dtype == torch.float32 else 5e-3)
