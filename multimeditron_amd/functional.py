@@ -1,0 +1,412 @@
+"""torch.autograd.Function wrappers: each forward/backward is one or a few libmmhip calls.  Activations are
+2-D token-major tensors [T, features] throughout (T = batch * seq), which is exactly what the GEMMs consume, so the
+path contains no transposes or permutes.
+
+Weight gradients are written straight into `param.grad` by the wgrad GEMM (overwrite on the first contribution of a
+step, accumulate afterwards) instead of being returned to autograd: no extra pass over 8 B parameters, and the DP
+trainer can point `.grad` at its flat all-reduce buckets.  See `grad_target`."""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from . import kernels as K
+from ._lib import EPI_GELU_ERF, EPI_QUICK_GELU
+
+# called as hook(param) right after a parameter's gradient for this step is complete (DP bucket scheduling)
+_grad_ready_hook: Optional[Callable] = None
+
+
+def set_grad_ready_hook(fn: Optional[Callable]):
+    global _grad_ready_hook
+    _grad_ready_hook = fn
+
+
+def grad_target(p: torch.Tensor):
+    """-> (grad buffer, accumulate?) for writing p's gradient in place."""
+    if p.grad is None:
+        view = getattr(p, "_mm_grad_view", None)
+        p.grad = view if view is not None else torch.empty_like(p)
+        fresh = True
+    else:
+        fresh = bool(getattr(p, "_mm_fresh", False))
+    p._mm_fresh = False
+    return p.grad, not fresh
+
+
+def _ready(p):
+    if _grad_ready_hook is not None:
+        _grad_ready_hook(p)
+
+
+class ParamGroup:
+    """One or several Parameters that are adjacent views of one flat buffer and act as a single GEMM operand
+    (fused q/k/v, fused gate/up).  `.tensor()` is the fused [sum_out, in] weight (or [sum_out] bias)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+
+    def _fused(self, get):
+        ts = [get(p) for p in self.params]
+        if len(ts) == 1:
+            return ts[0]
+        first = ts[0]
+        ptr = first.data_ptr()
+        for t in ts:
+            if t.data_ptr() != ptr or not t.is_contiguous():
+                return None
+            ptr += t.numel() * t.element_size()
+        rows = sum(t.shape[0] for t in ts)
+        shape = (rows,) + tuple(first.shape[1:])
+        return first.as_strided(shape, first.stride())
+
+    def tensor(self):
+        t = self._fused(lambda p: p.data)
+        if t is None:  # not packed (e.g. a freshly constructed CPU->GPU model before pack_parameters)
+            raise RuntimeError("fused parameter group is not contiguous in memory: call model.pack_parameters()")
+        return t
+
+    @property
+    def requires_grad(self):
+        return any(p.requires_grad for p in self.params)
+
+    def grad_target(self):
+        tg = [grad_target(p) for p in self.params]
+        if len(tg) == 1:
+            return tg[0]
+        accs = {a for _, a in tg}
+        g = self._fused(lambda p: p.grad)
+        if g is None or len(accs) != 1:
+            raise RuntimeError("fused parameter group has non-contiguous .grad buffers")
+        return g, accs.pop()
+
+    def ready(self):
+        for p in self.params:
+            _ready(p)
+
+
+def as_group(p):
+    return p if isinstance(p, ParamGroup) else ParamGroup([p])
+
+
+# --------------------------------------------------------------------------------------------------- linear
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) + residual.  x, y 2-D.  W/b are ParamGroups (not autograd inputs); `dummy` is a
+    requires-grad scalar that keeps the node in the graph when only the weights need gradients."""
+
+    @staticmethod
+    def forward(ctx, x, residual, dummy, wg: ParamGroup, bg: Optional[ParamGroup], act: int, ldc_pad: bool):
+        w = wg.tensor()
+        b = bg.tensor() if bg is not None else None
+        pre = None
+        if act and (x.requires_grad or wg.requires_grad):
+            pre = K.linear_fwd(x, w, bias=b)                      # keep the pre-activation for backward
+            y = K.gelu_fwd(pre, 0 if act == EPI_GELU_ERF else 1)
+            if residual is not None:
+                y = K.add(y, residual)
+        else:
+            y = K.linear_fwd(x, w, bias=b, residual=residual, act=act, ldc_pad=ldc_pad)
+        ctx.wg, ctx.bg, ctx.act = wg, bg, act
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre = ctx.saved_tensors
+        wg, bg = ctx.wg, ctx.bg
+        if dy.stride(-1) != 1 or (dy.stride(0) % 8):
+            dy = dy.contiguous()
+        dres = dy if ctx.has_res else None
+        if ctx.act:
+            dy = K.gelu_bwd(pre, dy, 0 if ctx.act == EPI_GELU_ERF else 1)
+        if bg is not None and bg.requires_grad:
+            g, acc = bg.grad_target()
+            K.colsum(dy, g, acc)
+            bg.ready()
+        if wg.requires_grad:
+            g, acc = wg.grad_target()
+            K.linear_wgrad(dy, x, g, acc)
+            wg.ready()
+        dx = K.linear_dgrad(dy, wg.tensor()) if ctx.needs_input_grad[0] else None
+        return dx, dres, None, None, None, None, None
+
+
+def linear(x, wg, bg=None, residual=None, act=0, ldc_pad=False, dummy=None):
+    return LinearFn.apply(x, residual, dummy, as_group(wg), as_group(bg) if bg is not None else None, act, ldc_pad)
+
+
+# --------------------------------------------------------------------------------------------------- norms
+class RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dummy, w, eps):
+        y, rstd = K.rmsnorm_fwd(x, w.data, eps)
+        ctx.w = w
+        ctx.save_for_backward(x, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, rstd = ctx.saved_tensors
+        w = ctx.w
+        dx, dwp = K.rmsnorm_bwd(dy.contiguous(), x, w.data, rstd)
+        if w.requires_grad:
+            g, acc = grad_target(w)
+            K.reduce_partials(dwp, g, acc)
+            _ready(w)
+        return dx, None, None, None
+
+
+def rmsnorm(x, w, eps, dummy=None):
+    return RMSNormFn.apply(x, dummy, w, eps)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dummy, w, b, eps):
+        y, mean, rstd = K.layernorm_fwd(x, w.data, b.data, eps)
+        ctx.w, ctx.b = w, b
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        dx, dwp, dbp = K.layernorm_bwd(dy.contiguous(), x, w.data, mean, rstd)
+        if w.requires_grad:
+            g, acc = grad_target(w)
+            K.reduce_partials(dwp, g, acc)
+            _ready(w)
+        if b.requires_grad:
+            g, acc = grad_target(b)
+            K.reduce_partials(dbp, g, acc)
+            _ready(b)
+        return dx, None, None, None, None
+
+
+def layernorm(x, w, b, eps, dummy=None):
+    return LayerNormFn.apply(x, dummy, w, b, eps)
+
+
+# --------------------------------------------------------------------------------------------------- attention
+class RopeAttentionFn(torch.autograd.Function):
+    """qkv [T, (Hq+2Hkv)*D] (fused projection output, consumed in place) -> out [T, Hq*D].
+    RoPE (optional) is applied in place to the q and k heads, then flash attention.  Returns roped k/v views via
+    ctx-free attributes for KV caching (see `attention`)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale):
+        W = (Hq + 2 * Hkv) * D
+        assert qkv.shape == (B * S, W) and qkv.is_contiguous()
+        if cos is not None:
+            K.rope_apply_(qkv, B * S, Hq + Hkv, D, W, cos, sin)
+        q = qkv[:, : Hq * D].view(B, S, Hq, D)
+        k = qkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D)
+        v = qkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+        out, lse = K.attn_fwd(q, k, v, key_mask, causal, scale)
+        ctx.dims = (B, S, Hq, Hkv, D, causal, scale)
+        ctx.save_for_backward(qkv, out, lse, cos, sin, key_mask)
+        return out.view(B * S, Hq * D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, cos, sin, key_mask = ctx.saved_tensors
+        B, S, Hq, Hkv, D, causal, scale = ctx.dims
+        W = (Hq + 2 * Hkv) * D
+        q = qkv[:, : Hq * D].view(B, S, Hq, D)
+        k = qkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D)
+        v = qkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+        dqkv = torch.zeros_like(qkv) if qkv.dtype == torch.float32 else torch.empty_like(qkv)
+        dq = dqkv[:, : Hq * D].view(B, S, Hq, D)
+        dk = dqkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D)
+        dv = dqkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+        K.attn_bwd(q, k, v, out, dout.contiguous().view(B, S, Hq, D), lse, key_mask, causal, scale, dq, dk, dv)
+        if cos is not None:
+            K.rope_apply_(dqkv, B * S, Hq + Hkv, D, W, cos, sin, inverse=True)
+        return (dqkv,) + (None,) * 10
+
+
+def rope_attention(qkv, cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale):
+    return RopeAttentionFn.apply(qkv, cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale)
+
+
+# --------------------------------------------------------------------------------------------------- activations
+class SwiGLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gu, I):
+        ctx.I = I
+        ctx.save_for_backward(gu)
+        return K.swiglu_fwd(gu, I)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gu,) = ctx.saved_tensors
+        return K.swiglu_bwd(gu, dout.contiguous(), ctx.I), None
+
+
+def swiglu(gu, I):
+    return SwiGLUFn.apply(gu, I)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.add(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+# --------------------------------------------------------------------------------------------------- embed + splice
+class EmbedSpliceFn(torch.autograd.Function):
+    """model.py:433-444 in one pass: token embedding gather with modality rows spliced in."""
+
+    @staticmethod
+    def forward(ctx, proj, dummy, emb, ids, batch_idx, token_range, B, S):
+        T = B * S
+        ids = ids.reshape(-1).contiguous()
+        src_map = None
+        if proj is not None:
+            src_map = K.splice_build_map(batch_idx, token_range, S, T)
+            proj = proj.reshape(-1, proj.shape[-1])
+            if proj.dtype != emb.dtype:   # model.py:443-444 casts the modality rows to the embedding dtype
+                proj = K.cast(proj, emb.dtype)
+            proj = proj.contiguous()
+        out = K.embed_splice_fwd(emb.data, ids, proj, src_map)
+        ctx.emb = emb
+        ctx.S = S
+        ctx.has_proj = proj is not None
+        ctx.proj_rows = proj.shape[0] if proj is not None else 0
+        ctx.save_for_backward(ids, src_map, batch_idx, token_range)
+        return out
+
+    @staticmethod
+    def backward(ctx, dE):
+        ids, src_map, batch_idx, token_range = ctx.saved_tensors
+        emb = ctx.emb
+        dE = dE.contiguous()
+        dproj = None
+        if ctx.has_proj and ctx.needs_input_grad[0]:
+            dproj = torch.empty((ctx.proj_rows, dE.shape[1]), dtype=dE.dtype, device=dE.device)
+        demb = None
+        if emb.requires_grad:
+            demb, acc = grad_target(emb)
+            if not acc:
+                demb.zero_()
+        K.embed_splice_bwd(dE, ids, src_map, batch_idx, token_range, ctx.S, dproj, demb)
+        if emb.requires_grad:
+            _ready(emb)
+        return dproj, None, None, None, None, None, None, None
+
+
+def embed_splice(emb, ids, proj, batch_idx, token_range, B, S, dummy=None):
+    return EmbedSpliceFn.apply(proj, dummy, emb, ids, batch_idx, token_range, B, S)
+
+
+# --------------------------------------------------------------------------------------------------- ViT glue
+class PatchEmbedFn(torch.autograd.Function):
+    """HF:clip:138-218: conv(k=s=patch) as patchify + GEMM, + CLS + position embedding."""
+
+    @staticmethod
+    def forward(ctx, pixels, dummy, w_conv, cls, pos, ps):
+        n = pixels.shape[0]
+        Dv = w_conv.shape[0]
+        kk = 3 * ps * ps
+        kpad = (kk + 63) // 64 * 64
+        dtype = w_conv.dtype
+        patches = K.patchify(pixels.contiguous(), ps, kpad, dtype)
+        wp = torch.zeros((Dv, kpad), dtype=dtype, device=w_conv.device)
+        wp[:, :kk].copy_(w_conv.data.reshape(Dv, kk))
+        po = K.linear_fwd(patches, wp)
+        P = patches.shape[0] // n
+        x = K.vit_embed_fwd(po, cls.data, pos.data, n, P)
+        ctx.params = (w_conv, cls, pos)
+        ctx.meta = (n, P, Dv, kk, kpad)
+        ctx.save_for_backward(patches)
+        return x.view(n * (P + 1), Dv)
+
+    @staticmethod
+    def backward(ctx, dx):
+        (patches,) = ctx.saved_tensors
+        w_conv, cls, pos = ctx.params
+        n, P, Dv, kk, kpad = ctx.meta
+        need_w = w_conv.requires_grad
+        gc = gp = None
+        accc = accp = False
+        if cls.requires_grad:
+            gc, accc = grad_target(cls)
+        if pos.requires_grad:
+            gp, accp = grad_target(pos)
+        if not (need_w or gc is not None or gp is not None):
+            return (None,) * 6
+        dx = dx.contiguous().view(n, P + 1, Dv)
+        if gc is not None and gp is not None and accc != accp:   # kernel takes one flag: normalise by zeroing
+            (gc if not accc else gp).zero_()
+            accc = accp = True
+        dpatch = K.vit_embed_bwd(dx, gc, gp, accc or accp, want_dpatch=need_w)
+        if need_w:
+            gw = torch.empty((Dv, kpad), dtype=dx.dtype, device=dx.device)
+            K.linear_wgrad(dpatch, patches, gw, False)
+            g, acc = grad_target(w_conv)
+            if acc:
+                g.add_(gw[:, :kk].reshape(g.shape))
+            else:
+                g.copy_(gw[:, :kk].reshape(g.shape))
+            _ready(w_conv)
+        for p in (cls, pos):
+            if p.requires_grad:
+                _ready(p)
+        return (None,) * 6
+
+
+def patch_embed(pixels, w_conv, cls, pos, ps, dummy=None):
+    return PatchEmbedFn.apply(pixels, dummy, w_conv, cls, pos, ps)
+
+
+class DropClsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n, T):
+        return K.drop_cls_fwd(x.view(n, T, -1))
+
+    @staticmethod
+    def backward(ctx, dy):
+        d = K.drop_cls_bwd(dy.contiguous())
+        return d.view(-1, d.shape[-1]), None, None
+
+
+def drop_cls(x, n, T):
+    return DropClsFn.apply(x, n, T)
+
+
+# --------------------------------------------------------------------------------------------------- loss
+class CausalLMLossFn(torch.autograd.Function):
+    """HF:loss/loss_utils.py:36-71 on the (padded-stride) logits: mean CE over labels != -100, labels pre-shifted."""
+
+    @staticmethod
+    def forward(ctx, logits2d, V, shift_labels):
+        lc, lse = K.ce_fwd(logits2d, V, shift_labels)
+        ctx.V = V
+        ctx.save_for_backward(logits2d, shift_labels, lse, lc)
+        return lc[0].clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits2d, labels, lse, lc = ctx.saved_tensors
+        T = logits2d.shape[0]
+        ld = logits2d.stride(0)
+        buf = torch.empty((T, ld), dtype=logits2d.dtype, device=logits2d.device)
+        d = buf[:, : logits2d.shape[1]]
+        g = dloss.reshape(1).to(torch.float32).contiguous()
+        K.ce_bwd(logits2d, ctx.V, labels, lse, lc, g, d)
+        return d, None, None
+
+
+def causal_lm_loss(logits2d, V, shift_labels):
+    return CausalLMLossFn.apply(logits2d, V, shift_labels)

@@ -1,0 +1,272 @@
+"""Llama / Qwen2 decoder on libmmhip kernels: the MI355X replacement for the HF `AutoModelForCausalLM` the
+reference constructs at model.py:253-260 and calls at model.py:517-526 (forward) and :595-602 (decode).
+
+Semantics follow HF transformers 5.15.0 (models/llama/modeling_llama.py): RMSNorm :53-70, RoPE :113-160 (+ llama3
+inv_freq scaling modeling_rope_utils.py:641-662), GQA softmax attention :191-281, SwiGLU MLP :163-176, pre-norm
+residual layer :284-325, final norm + lm_head :413,480, shifted CE loss/loss_utils.py:36-71.  Qwen2 = same graph with
+biased q/k/v projections.  Parameter names equal HF's so reference checkpoints interchange.
+
+Data layout: activations are [B*S, features] row-major in HBM; q/k/v come out of ONE fused GEMM as a
+[B*S, (Hq+2Hkv)*D] buffer that RoPE rewrites in place and the attention kernel reads through strides; gate/up come
+out of one fused GEMM as [B*S, 2I]; the residual add is the GEMM epilogue of o_proj/down_proj."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fm
+from .. import kernels as K
+from ..nn import Embedding, Linear, Norm, grad_dummy
+
+
+@dataclass
+class LLMConfig:
+    model_type: str = "llama"
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: Optional[int] = None
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    tie_word_embeddings: bool = False
+    attention_bias: bool = False
+    max_position_embeddings: int = 131072
+    rope_parameters: Dict[str, Any] = field(default_factory=lambda: {"rope_type": "default", "rope_theta": 10000.0})
+
+    @classmethod
+    def from_dict(cls, d: Dict[str, Any]) -> "LLMConfig":
+        d = dict(d)
+        rp = d.get("rope_parameters")
+        if not rp:   # older HF layout: rope_theta + rope_scaling
+            rp = dict(d.get("rope_scaling") or {})
+            rp.setdefault("rope_type", rp.pop("type", "default"))
+            rp.setdefault("rope_theta", d.get("rope_theta", 10000.0))
+        mt = d.get("model_type", "llama")
+        known = {f for f in cls.__dataclass_fields__}
+        kw = {k: v for k, v in d.items() if k in known}
+        kw["rope_parameters"] = rp
+        if mt.startswith("qwen2"):
+            kw["attention_bias"] = True          # Qwen2 hard-codes biased q/k/v (HF:models/qwen2)
+        if not kw.get("head_dim"):
+            kw["head_dim"] = kw.get("hidden_size", 4096) // kw.get("num_attention_heads", 32)
+        return cls(**kw)
+
+    def to_dict(self):
+        return {k: getattr(self, k) for k in self.__dataclass_fields__}
+
+
+def rope_inv_freq(cfg: LLMConfig) -> torch.Tensor:
+    rp = cfg.rope_parameters
+    base = float(rp.get("rope_theta", 10000.0))
+    hd = cfg.head_dim
+    inv = 1.0 / (base ** (torch.arange(0, hd, 2, dtype=torch.int64).to(torch.float32) / hd))
+    if rp.get("rope_type", "default") == "llama3":
+        factor, lo, hi = rp["factor"], rp["low_freq_factor"], rp["high_freq_factor"]
+        old = rp["original_max_position_embeddings"]
+        wavelen = 2 * math.pi / inv
+        scaled = torch.where(wavelen > old / lo, inv / factor, inv)
+        smooth = (old / wavelen - lo) / (hi - lo)
+        mid = (1 - smooth) * scaled / factor + smooth * scaled
+        is_mid = ~(wavelen < old / hi) * ~(wavelen > old / lo)
+        inv = torch.where(is_mid, mid, scaled)
+    return inv
+
+
+class Attention(nn.Module):
+    def __init__(self, cfg: LLMConfig, dtype, device):
+        super().__init__()
+        H, D = cfg.hidden_size, cfg.head_dim
+        self.Hq, self.Hkv, self.D = cfg.num_attention_heads, cfg.num_key_value_heads, D
+        b = cfg.attention_bias
+        self.q_proj = Linear(H, self.Hq * D, bias=b, dtype=dtype, device=device)
+        self.k_proj = Linear(H, self.Hkv * D, bias=b, dtype=dtype, device=device)
+        self.v_proj = Linear(H, self.Hkv * D, bias=b, dtype=dtype, device=device)
+        self.o_proj = Linear(self.Hq * D, H, bias=False, dtype=dtype, device=device)
+        self._wqkv = Fm.ParamGroup([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])
+        self._bqkv = Fm.ParamGroup([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]) if b else None
+
+
+class MLP(nn.Module):
+    def __init__(self, cfg: LLMConfig, dtype, device):
+        super().__init__()
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        self.I = I
+        self.gate_proj = Linear(H, I, bias=False, dtype=dtype, device=device)
+        self.up_proj = Linear(H, I, bias=False, dtype=dtype, device=device)
+        self.down_proj = Linear(I, H, bias=False, dtype=dtype, device=device)
+        self._wgu = Fm.ParamGroup([self.gate_proj.weight, self.up_proj.weight])
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, cfg: LLMConfig, dtype, device):
+        super().__init__()
+        self.self_attn = Attention(cfg, dtype, device)
+        self.mlp = MLP(cfg, dtype, device)
+        self.input_layernorm = Norm(cfg.hidden_size, cfg.rms_norm_eps, bias=False, dtype=dtype, device=device)
+        self.post_attention_layernorm = Norm(cfg.hidden_size, cfg.rms_norm_eps, bias=False, dtype=dtype, device=device)
+
+    def forward(self, x, cos, sin, key_mask, B, S, cache=None):
+        a = self.self_attn
+        h = self.input_layernorm(x)
+        qkv = Fm.linear(h, a._wqkv, a._bqkv, dummy=grad_dummy(a.q_proj.weight))
+        if cache is None:
+            o = Fm.rope_attention(qkv, cos, sin, key_mask, B, S, a.Hq, a.Hkv, a.D, True, a.D ** -0.5)
+        else:
+            o = cache.attend(qkv, cos, sin, key_mask, B, S, a)
+        x = a.o_proj(o, residual=x)
+        h = self.post_attention_layernorm(x)
+        gu = Fm.linear(h, self.mlp._wgu, None, dummy=grad_dummy(self.mlp.gate_proj.weight))
+        act = Fm.swiglu(gu, self.mlp.I)
+        return self.mlp.down_proj(act, residual=x)
+
+
+class LayerKVCache:
+    """Contiguous per-layer KV cache [B, Smax, Hkv, D] for the decode loop of generate (model.py:581-638)."""
+
+    def __init__(self, B, Smax, Hkv, D, dtype, device):
+        self.k = torch.zeros((B, Smax, Hkv, D), dtype=dtype, device=device)
+        self.v = torch.zeros((B, Smax, Hkv, D), dtype=dtype, device=device)
+        self.len = 0
+
+    @torch.no_grad()
+    def attend(self, qkv, cos, sin, key_mask, B, S, a: Attention):
+        Hq, Hkv, D = a.Hq, a.Hkv, a.D
+        W = (Hq + 2 * Hkv) * D
+        K.rope_apply_(qkv, B * S, Hq + Hkv, D, W, cos, sin)
+        q = qkv[:, : Hq * D].view(B, S, Hq, D)
+        kn = qkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D)
+        vn = qkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+        self.k[:, self.len:self.len + S].copy_(kn)      # device-side memory plumbing
+        self.v[:, self.len:self.len + S].copy_(vn)
+        self.len += S
+        out, _ = K.attn_fwd(q, self.k[:, : self.len], self.v[:, : self.len], key_mask, True, D ** -0.5)
+        return out.view(B * S, Hq * D)
+
+
+class DecoderModel(nn.Module):
+    def __init__(self, cfg: LLMConfig, dtype, device):
+        super().__init__()
+        self.embed_tokens = Embedding(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device)
+        self.layers = nn.ModuleList([DecoderLayer(cfg, dtype, device) for _ in range(cfg.num_hidden_layers)])
+        self.norm = Norm(cfg.hidden_size, cfg.rms_norm_eps, bias=False, dtype=dtype, device=device)
+
+
+@dataclass
+class CausalLMOutput:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[Any] = None
+    hidden_states: Optional[Any] = None
+    attentions: Optional[Any] = None
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else (self.loss, self.logits, self.past_key_values)[k]
+
+
+class CausalLM(nn.Module):
+    """`self.model` of MultiModalModelForCausalLM (reference attribute name, model.py:253-262)."""
+
+    def __init__(self, cfg: LLMConfig, dtype=torch.bfloat16, device=None):
+        super().__init__()
+        self.config = cfg
+        self.model = DecoderModel(cfg, dtype, device)
+        self.lm_head = Linear(cfg.hidden_size, cfg.vocab_size, bias=False, dtype=dtype, device=device)
+        if cfg.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+        self._inv_freq = None
+
+    # -- reference surface -------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.model.embed_tokens.weight.device
+
+    @property
+    def dtype(self):
+        return self.model.embed_tokens.weight.dtype
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.model.embed_tokens = value
+
+    def resize_token_embeddings(self, new_num_tokens: int, mean_resizing: bool = False, std: float = 0.02):
+        """model.py:262.  New rows ~ N(0, std) (mean_resizing=False semantics); tied heads stay tied."""
+        emb = self.model.embed_tokens
+        old = emb.num_embeddings
+        if new_num_tokens == old:
+            return emb
+
+        def grow(w):
+            nw = torch.empty((new_num_tokens, w.shape[1]), dtype=w.dtype, device=w.device)
+            n = min(old, new_num_tokens)
+            nw[:n] = w.data[:n]
+            if new_num_tokens > old:
+                nw[old:].normal_(mean=0.0, std=std)
+            return nn.Parameter(nw, requires_grad=w.requires_grad)
+
+        tied = self.lm_head.weight is emb.weight
+        emb.weight = grow(emb.weight)
+        emb.num_embeddings = new_num_tokens
+        self.lm_head.weight = emb.weight if tied else grow(self.lm_head.weight)
+        self.lm_head.out_features = new_num_tokens
+        self.config.vocab_size = new_num_tokens
+        return emb
+
+    # -- compute --------------------------------------------------------------------------------------
+    def _tables(self, position_ids):
+        if self._inv_freq is None or self._inv_freq.device != position_ids.device:
+            self._inv_freq = rope_inv_freq(self.config).to(position_ids.device)
+        return K.rope_table(position_ids.reshape(-1).contiguous(), self._inv_freq, self.dtype == torch.bfloat16)
+
+    def new_cache(self, B, Smax):
+        c = self.config
+        return [LayerKVCache(B, Smax, c.num_key_value_heads, c.head_dim, self.dtype, self.device)
+                for _ in range(c.num_hidden_layers)]
+
+    def forward(self, input_ids=None, inputs_embeds=None, attention_mask=None, position_ids=None,
+                past_key_values=None, labels=None, use_cache=None, return_dict=True, logits_to_keep: int = 0, **kwargs):
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if inputs_embeds is None:
+            inputs_embeds = self.model.embed_tokens(input_ids)
+        B, S, H = inputs_embeds.shape
+        dev = inputs_embeds.device
+        cache = past_key_values
+        past = cache[0].len if cache else 0
+        if use_cache and cache is None:
+            cache = self.new_cache(B, S + int(kwargs.get("max_new_tokens", 512)))
+        if position_ids is None:
+            position_ids = (torch.arange(S, device=dev) + past).unsqueeze(0).expand(B, S)
+        cos, sin = self._tables(position_ids.to(dev))
+        key_mask = None
+        if attention_mask is not None:
+            key_mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        x = inputs_embeds.reshape(B * S, H)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        for i, layer in enumerate(self.model.layers):
+            x = layer(x, cos, sin, key_mask, B, S, cache=cache[i] if cache else None)
+        x = self.model.norm(x)
+        V = self.config.vocab_size
+        if logits_to_keep:
+            x = x.view(B, S, H)[:, -logits_to_keep:, :].reshape(-1, H)
+            Sk = logits_to_keep
+        else:
+            Sk = S
+        logits2d = self.lm_head(x, ldc_pad=True)                 # [B*Sk, V] view, row stride padded to 64
+        loss = None
+        if labels is not None:
+            shift = torch.nn.functional.pad(labels.to(dev), (0, 1), value=-100)[..., 1:].reshape(-1).contiguous()
+            loss = Fm.causal_lm_loss(logits2d, V, shift)
+        logits = logits2d.as_strided((B, Sk, V), (Sk * logits2d.stride(0), logits2d.stride(0), 1))
+        out = CausalLMOutput(loss=loss, logits=logits, past_key_values=cache if use_cache else None)
+        return out if return_dict else (loss, logits, out.past_key_values)
+
+    __call__ = nn.Module.__call__

@@ -1,0 +1,389 @@
+"""Drop-in for the reference's `multimeditron.model.model` (model.py:17-673): `ChatTemplate`, `MultimodalConfig`,
+`MultiModalModelForCausalLM` (forward / generate / freeze policies / processors) and `bootstrap`, with the whole
+numerical path -- modality encoder, projector, embed-splice, decoder, loss -- on libmmhip (gfx950) kernels.
+
+Differences from the reference that a caller can observe (all documented in DESIGN.md):
+  * the LLM and the CLIP tower are this package's own modules (model/llm.py, model/vision.py), not HF classes;
+    parameter names are identical so checkpoints interchange; hub names resolve to built-in shape presets;
+  * `forward` returns a small dataclass with `.loss`, `.logits`, `.past_key_values` (HF `CausalLMOutputWithPast` shape);
+    `.logits` is a [B,S,V] view whose row stride is padded to a multiple of 64 elements;
+  * there is no eager/CPU fallback: without libmmhip.so and a GPU every compute call raises."""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fm
+from .. import kernels as K
+from ..nn import FlatParams, grad_dummy
+from ..utils import get_torch_dtype
+from .llm import CausalLM, CausalLMOutput, LLMConfig
+from .modalities import AutoModality, BaseModality, BaseModalityConfig, BaseModalityProcessor
+from .presets import resolve_llm_config
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class ChatTemplate:
+    """Role delimiters + special tokens per LLM family (reference model.py:17-99)."""
+    name: str = "custom"
+    delimiters: Dict[str, Dict[str, str]] = field(default_factory=dict)
+    special_tokens: Dict[str, str] = field(default_factory=dict)
+
+    _IMAGE_TOKENS = {"image_start": "<|image_start|>", "image_end": "<|image_end|>"}
+
+    @staticmethod
+    def from_name(name: str) -> "ChatTemplate":
+        makers = {"llama": ChatTemplate.llama, "apertus": ChatTemplate.apertus, "qwen3": ChatTemplate.qwen3}
+        if name not in makers:
+            raise ValueError(f"Unknown chat template name: {name}")
+        return makers[name]()
+
+    @staticmethod
+    def _make(name, roles):
+        return ChatTemplate(name=name, delimiters={r: {"start": s, "end": e} for r, (s, e) in roles.items()},
+                            special_tokens=dict(ChatTemplate._IMAGE_TOKENS))
+
+    @staticmethod
+    def llama() -> "ChatTemplate":
+        hdr = "<|start_header_id|>{}<|end_header_id|>"
+        return ChatTemplate._make("llama", {r: (hdr.format(r), "<|eot_id|>") for r in ("system", "user", "assistant")})
+
+    @staticmethod
+    def apertus() -> "ChatTemplate":
+        return ChatTemplate._make("apertus", {r: (f"<|{r}_start|>", f"<|{r}_end|>")
+                                              for r in ("system", "developer", "user", "assistant")})
+
+    @staticmethod
+    def qwen3() -> "ChatTemplate":
+        return ChatTemplate._make("qwen3", {r: (f"<|im_start|>{r}", "<|im_end|>") for r in ("system", "user", "assistant")})
+
+
+class MultimodalConfig:
+    """reference model.py:103-202 (same constructor arguments and dict layout)."""
+    model_type = "multimodal"
+
+    def __init__(self, vocab_size: Optional[int] = None, modalities: List[BaseModalityConfig] = (), pad_token_idx: int = 0,
+                 eos_token_idx: int = 0, padding_side: str = "left", initializer_range: float = 0.02,
+                 llm_path: str = "meta-llama/Llama-3.1-8B-Instruct", truncation: bool = False,
+                 max_sequence_length: Optional[int] = None, dtype="bfloat16", **kwargs):
+        self.vocab_size = vocab_size
+        self.modalities = list(modalities)
+        self.pad_token_idx = pad_token_idx
+        self.eos_token_idx = eos_token_idx
+        self.padding_side = padding_side
+        self.initializer_range = initializer_range
+        self.llm_path = llm_path
+        self.dtype = dtype
+        self.truncation = truncation
+        self.max_sequence_length = max_sequence_length
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def to_dict(self):
+        out = {k: v for k, v in self.__dict__.items() if not k.startswith("_") and k != "modalities"}
+        out["dtype"] = str(out["dtype"]).replace("torch.", "")
+        out["model_type"] = self.model_type
+        out["modalities"] = [m.to_dict() for m in self.modalities]
+        return out
+
+    @classmethod
+    def from_dict(cls, config_dict, **kwargs):
+        d = dict(config_dict)
+        d.pop("model_type", None)
+        d.pop("torch_dtype", None)
+        mods = [AutoModality.config_from_dict(m) for m in d.pop("modalities", [])]
+        d.update(kwargs)
+        return cls(modalities=mods, **d)
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, sort_keys=True, default=str)
+
+
+class MultiModalModelForCausalLM(nn.Module):
+    config_class = MultimodalConfig
+    base_model_prefix = "model"
+    supports_gradient_checkpointing = True
+
+    def __init__(self, config: MultimodalConfig, bootstrap=False, device=None, llm_config: Optional[dict] = None):
+        """`bootstrap` is accepted for signature parity (model.py:226-230): there is no hub here, so both branches build
+        the LLM from `config.llm_path`'s config.json / preset with random init; local weights are loaded by
+        `load_state_dict` / `from_pretrained`."""
+        super().__init__()
+        self.config = config
+        dtype = get_torch_dtype(config.dtype)
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self._llm_cfg = LLMConfig.from_dict(llm_config if llm_config is not None else resolve_llm_config(config.llm_path))
+        self.model = CausalLM(self._llm_cfg, dtype=dtype, device=device)
+        self.modalities_by_type: Dict[str, BaseModality] = {}
+        self.processors_by_type: Dict[str, BaseModalityProcessor] = {}
+        self.modalities_with_projection = nn.ModuleList()
+        for mc in config.modalities:
+            modality = AutoModality.model_from_config(mc, dtype=dtype, device=device)
+            processor = AutoModality.preprocessor_from_name(mc.model_type, mc)
+            if mc.modality_type in self.modalities_by_type:
+                raise ValueError(f"Modality type {mc.modality_type} has already been registered")
+            self.modalities_by_type[mc.modality_type] = modality
+            self.processors_by_type[mc.modality_type] = processor
+            self.modalities_with_projection.append(modality)
+        self.apply(self._init_weights)
+        if config.vocab_size is not None:
+            self.model.resize_token_embeddings(config.vocab_size, mean_resizing=False, std=config.initializer_range)
+        self._flat: Optional[FlatParams] = None
+
+    # ------------------------------------------------------------------ init / packing
+    def _init_weights(self, module):
+        """model.py:287-308: N(0, initializer_range) weights, zero biases; norms keep (1, 0)."""
+        from ..nn import Embedding, Linear, Norm
+        std = self.config.initializer_range
+        with torch.no_grad():
+            if isinstance(module, Linear):
+                module.weight.normal_(mean=0.0, std=std)
+                if module.bias is not None:
+                    module.bias.zero_()
+            elif isinstance(module, Embedding):
+                module.weight.normal_(mean=0.0, std=std)
+            elif isinstance(module, Norm):
+                module.weight.fill_(1.0)
+                if module.bias is not None:
+                    module.bias.zero_()
+            else:
+                for n, p in module.named_parameters(recurse=False):   # class/position embeddings, patch conv
+                    p.normal_(mean=0.0, std=std)
+
+    def _component_params(self):
+        seen, out = set(), []
+        for n, p in self.model.named_parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(("model." + n, p, "llm"))
+        for i, m in enumerate(self.modalities_with_projection):
+            for n, p in m.named_parameters():
+                if id(p) in seen:
+                    continue
+                seen.add(id(p))
+                comp = f"projector{i}" if n.startswith("projector.") else f"encoder{i}"
+                out.append((f"modalities_with_projection.{i}.{n}", p, comp))
+        return out
+
+    def pack_parameters(self) -> FlatParams:
+        """Lay all parameters out in one flat buffer (fused q/k/v and gate/up operands, flat grads, flat AdamW)."""
+        params = self._component_params()
+        dtype = get_torch_dtype(self.config.dtype)
+        dev = params[0][1].device
+        self._flat = FlatParams(params, dev, dtype)
+        return self._flat
+
+    def flat_params(self) -> FlatParams:
+        if self._flat is None:
+            self.pack_parameters()
+        return self._flat
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._flat = None            # views into the old flat buffer are gone: re-pack lazily
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = dict(state_dict)
+        own = dict(self.named_parameters())
+        # the reference keeps the whole CLIPModel; accept and ignore its unused towers / buffers
+        unused = [k for k in sd if k not in own and any(t in k for t in ("text_model", "text_projection", "visual_projection",
+                                                                         "logit_scale", "position_ids", "post_layernorm"))]
+        for k in unused:
+            sd.pop(k)
+        if "model.lm_head.weight" in sd and self._llm_cfg.tie_word_embeddings:
+            sd.pop("model.lm_head.weight")
+        missing = [k for k in own if k not in sd]
+        extra = [k for k in sd if k not in own]
+        if strict and (missing or extra):
+            raise RuntimeError(f"load_state_dict: missing={missing[:5]}... unexpected={extra[:5]}...")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(v.to(device=own[k].device, dtype=own[k].dtype).reshape(own[k].shape))
+        return missing, extra
+
+    def save_pretrained(self, path: str):
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        self.config.save_pretrained(path)
+        with open(os.path.join(path, "llm_config.json"), "w") as f:
+            json.dump(self._llm_cfg.to_dict(), f, indent=2)
+        sd = {k: v.detach().cpu().contiguous().clone() for k, v in self.named_parameters()}
+        save_file(sd, os.path.join(path, "model.safetensors"))
+
+    @classmethod
+    def from_pretrained(cls, path: str, device=None, **kwargs):
+        from safetensors.torch import load_file
+        cfg = MultimodalConfig.from_dict(json.load(open(os.path.join(path, "config.json"))))
+        llm_cfg = None
+        p = os.path.join(path, "llm_config.json")
+        if os.path.exists(p):
+            llm_cfg = json.load(open(p))
+        model = cls(cfg, device=device, llm_config=llm_cfg)
+        model.load_state_dict(load_file(os.path.join(path, "model.safetensors")), strict=False)
+        return model
+
+    # ------------------------------------------------------------------ freeze policies (model.py:310-377)
+    def freeze_for_alignment(self):
+        for m in self.modalities_with_projection:
+            m.unfreeze_projection()
+            m.freeze_modality_embedder()
+        for p in self.model.parameters():
+            p.requires_grad = False
+
+    def freeze_for_lm(self):
+        for m in self.modalities_with_projection:
+            m.freeze_all()
+        for p in self.model.parameters():
+            p.requires_grad = True
+
+    def freeze_for_end2end(self):
+        for m in self.modalities_with_projection:
+            m.unfreeze_projection()
+            m.freeze_modality_embedder()
+        for p in self.model.parameters():
+            p.requires_grad = True
+
+    def unfreeze(self):
+        for m in self.modalities_with_projection:
+            m.unfreeze_all()
+        for p in self.model.parameters():
+            p.requires_grad = True
+
+    # ------------------------------------------------------------------ accessors (model.py:379-408)
+    def processors(self) -> Dict[str, BaseModalityProcessor]:
+        return self.processors_by_type
+
+    def get_model(self):
+        return self.model
+
+    def _get_modality_by_name(self, name: str) -> BaseModality:
+        if name not in self.modalities_by_type:
+            raise KeyError(f"No modality registered in the model that can handle modality named: {name}")
+        modality = self.modalities_by_type[name]
+        if not isinstance(modality, BaseModality):
+            raise TypeError(f"Registered modality {name} is not of type ModalityWithProjection")
+        return modality
+
+    def get_input_embeddings(self):
+        return self.model.get_input_embeddings()
+
+    def set_input_embeddings(self, value):
+        self.model.set_input_embeddings(value)
+
+    @property
+    def device(self):
+        return self.model.device
+
+    @property
+    def dtype(self):
+        return self.model.dtype
+
+    # ------------------------------------------------------------------ the hot path
+    def embed_modalities_with_text(self, input_ids: torch.Tensor, processed_multimodal_inputs, stages=None):
+        """model.py:410-446 as ONE gather pass: out[b,s] = projected modality row if (b,s) is in
+        (batch_idx, token_range) else embedding[input_ids[b,s]]."""
+        if self._flat is None:
+            self.pack_parameters()
+        dev = self.device
+        emb = self.model.get_input_embeddings().weight
+        input_ids = input_ids.to(dev)
+        B, S = input_ids.shape
+        projs, bis, trs = [], [], []
+        pmi = processed_multimodal_inputs or {}
+        for name, stack in (pmi.get("stacked") or {}).items():
+            if len(stack) == 0:
+                continue
+            modality = self._get_modality_by_name(name)
+            e = modality(stack, stages=stages) if stages is not None else modality(stack)
+            projs.append(e.reshape(-1, e.shape[-1]))
+            bis.append(pmi["batch_idx"][name].to(dev))
+            trs.append(pmi["token_range"][name].to(dev))
+        proj = bi = tr = None
+        if projs:
+            proj = projs[0] if len(projs) == 1 else torch.cat(projs, dim=0)
+            bi = (bis[0] if len(bis) == 1 else torch.cat(bis)).to(torch.int64).contiguous()
+            tr = (trs[0] if len(trs) == 1 else torch.cat(trs)).to(torch.int64).contiguous()
+        out = Fm.embed_splice(emb, input_ids, proj, bi, tr, B, S, dummy=grad_dummy(emb))
+        return out.view(B, S, -1)
+
+    def forward(self, input_ids: torch.LongTensor = None, inputs_embeds: Optional[torch.Tensor] = None,
+                attention_mask: Optional[torch.Tensor] = None, position_ids: Optional[torch.LongTensor] = None,
+                past_key_values=None, labels: Optional[torch.LongTensor] = None, use_cache: Optional[bool] = None,
+                multimodal_inputs=None, processed_multimodal_inputs=None, return_dict: Optional[bool] = True,
+                cache_position=None, **kwargs) -> Union[tuple, CausalLMOutput]:
+        if self._flat is None:
+            self.pack_parameters()
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_modalities_with_text(input_ids, processed_multimodal_inputs)
+        msl = self.config.max_sequence_length
+        if self.config.truncation and msl is not None and inputs_embeds.shape[1] > msl:
+            logger.warning(f"Truncating input to {msl} tokens.")
+            inputs_embeds = inputs_embeds[:, :msl, :]
+            labels = labels[:, :msl] if labels is not None else None
+            attention_mask = attention_mask[:, :msl] if attention_mask is not None else None
+            position_ids = position_ids[:, :msl] if position_ids is not None else None
+        return self.model(inputs_embeds=inputs_embeds, attention_mask=attention_mask, position_ids=position_ids,
+                          past_key_values=past_key_values, use_cache=use_cache, labels=labels, return_dict=return_dict,
+                          **kwargs)
+
+    def generate(self, batch: Dict[str, Any], max_new_tokens=512, temperature=0.1, do_sample=True, **kwargs) -> torch.Tensor:
+        """model.py:528-640: KV-cache decode.  Token choice = argmax(softmax(logits/T)) (one kernel) or a per-row
+        multinomial draw; decode position = padded prompt length + i - 1 for every row (reference quirk :582-586);
+        rows that already emitted eos keep emitting eos; returns [B, n_new] int64 on CPU without the prompt."""
+        if self._flat is None:
+            self.pack_parameters()
+        dev = self.device
+        input_ids = batch["input_ids"].to(dev)
+        temperature = max(temperature, 1e-6)
+        B = input_ids.shape[0]
+        V = self._llm_cfg.vocab_size
+        eos = self.config.eos_token_idx
+        generated = []
+        finished = torch.zeros(B, dtype=torch.bool)
+        with torch.no_grad():
+            nxt = self.embed_modalities_with_text(input_ids, batch["processed_multimodal_inputs"])
+            attention_mask = batch["attention_mask"].to(dev)
+            position_ids = batch["position_ids"].to(dev)
+            seq_length = attention_mask.shape[1]
+            cache = self.model.new_cache(B, seq_length + max_new_tokens)
+            for i in range(max_new_tokens):
+                if i > 0:
+                    position_ids = torch.full((B, 1), seq_length + i - 1, dtype=torch.long, device=dev)
+                    attention_mask = torch.cat([attention_mask, torch.ones((B, 1), dtype=attention_mask.dtype, device=dev)], dim=-1)
+                out = self.model(inputs_embeds=nxt, attention_mask=attention_mask, position_ids=position_ids,
+                                 past_key_values=cache, use_cache=True, logits_to_keep=1)
+                logits2d = out.logits[:, -1, :]                       # [B, V] view, stride padded
+                if do_sample:
+                    probs = torch.softmax(logits2d.float() / temperature, dim=-1)
+                    tok = torch.cat([torch.multinomial(p, num_samples=1) for p in probs]).cpu()
+                else:
+                    tok = K.argmax_softmax(logits2d, V, temperature).cpu()
+                tok = torch.where(finished, torch.full_like(tok, eos), tok)
+                generated.append(tok)
+                finished = finished | (tok == eos)
+                if bool(finished.all()):
+                    break
+                nxt = self.model.get_input_embeddings()(tok.to(dev).view(B, 1))
+        return torch.stack(generated, dim=1)
+
+
+def bootstrap(config, tokenizer, modalities_config):
+    """reference model.py:643-671"""
+    mc = MultimodalConfig(hidden_size=config["token_size"], vocab_size=len(tokenizer),
+                          eos_token_idx=tokenizer.convert_tokens_to_ids(tokenizer.eos_token), modalities=modalities_config,
+                          llm_path=config["base_llm"], truncation=config.get("truncation", False),
+                          max_sequence_length=config.get("max_sequence_length", None))
+    return MultiModalModelForCausalLM(mc, bootstrap=True)

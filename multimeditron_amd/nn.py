@@ -1,0 +1,147 @@
+"""Parameter holders with the reference's state-dict names, and parameter packing.
+
+Modules here own Parameters only; the math is in functional.py (libmmhip kernels).  `pack_parameters` lays all
+parameters of a model out in one flat buffer per dtype so that (a) q/k/v and gate/up weights are adjacent and act
+as single fused GEMM operands, (b) gradients live in one flat buffer that doubles as the RCCL all-reduce buckets,
+(c) AdamW is one launch per contiguous trainable range."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fm
+
+
+class Linear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, dtype=None, device=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, dtype=dtype, device=device))
+        self.bias = nn.Parameter(torch.empty(out_features, dtype=dtype, device=device)) if bias else None
+
+    def forward(self, x2d, residual=None, act=0, ldc_pad=False):
+        return Fm.linear(x2d, self.weight, self.bias, residual=residual, act=act, ldc_pad=ldc_pad,
+                         dummy=grad_dummy(self.weight))
+
+    def extra_repr(self):
+        return f"in={self.in_features}, out={self.out_features}, bias={self.bias is not None}"
+
+
+class Embedding(nn.Module):
+    def __init__(self, num, dim, dtype=None, device=None):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim = num, dim
+        self.weight = nn.Parameter(torch.empty(num, dim, dtype=dtype, device=device))
+
+    def forward(self, ids):
+        """Plain lookup (no splice) -> [*ids.shape, dim]."""
+        B = ids.shape[0] if ids.dim() > 1 else 1
+        S = ids.numel() // B
+        out = Fm.embed_splice(self.weight, ids, None, None, None, B, S, dummy=grad_dummy(self.weight))
+        return out.view(*ids.shape, self.embedding_dim)
+
+
+class Norm(nn.Module):
+    """weight (+bias) holder for RMSNorm / LayerNorm."""
+
+    def __init__(self, dim, eps, bias: bool, dtype=None, device=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim, dtype=dtype, device=device))
+        self.bias = nn.Parameter(torch.zeros(dim, dtype=dtype, device=device)) if bias else None
+
+    def forward(self, x2d):
+        d = grad_dummy(self.weight)
+        if self.bias is None:
+            return Fm.rmsnorm(x2d, self.weight, self.eps, dummy=d)
+        return Fm.layernorm(x2d, self.weight, self.bias, self.eps, dummy=d)
+
+
+_dummies: Dict[str, torch.Tensor] = {}
+
+
+def grad_dummy(param: torch.Tensor) -> Optional[torch.Tensor]:
+    """A requires-grad scalar that keeps a custom Function in the autograd graph when only its (non-input)
+    parameters need gradients.  None when nothing here is trainable, so frozen towers record no graph."""
+    if not (torch.is_grad_enabled() and param.requires_grad):
+        return None
+    key = str(param.device)
+    d = _dummies.get(key)
+    if d is None:
+        d = torch.zeros(1, device=param.device, requires_grad=True)
+        _dummies[key] = d
+    return d
+
+
+# ------------------------------------------------------------------------------------------------------ packing
+class FlatSegment:
+    __slots__ = ("name", "start", "end", "decay", "component", "param")
+
+    def __init__(self, name, start, end, decay, component, param):
+        self.name, self.start, self.end, self.decay, self.component, self.param = name, start, end, decay, component, param
+
+
+class FlatParams:
+    """Flat parameter + gradient storage for one model (single dtype)."""
+
+    def __init__(self, named_params: List[Tuple[str, nn.Parameter, str]], device, dtype):
+        # order: per component, matrices (decayed) first, then vectors (not decayed); fused groups stay adjacent
+        # because they are adjacent in module order.
+        ordered = []
+        comps = []
+        for _, _, c in named_params:
+            if c not in comps:
+                comps.append(c)
+        for c in comps:
+            mats = [(n, p) for n, p, cc in named_params if cc == c and p.dim() >= 2]
+            vecs = [(n, p) for n, p, cc in named_params if cc == c and p.dim() < 2]
+            ordered += [(n, p, c, True) for n, p in mats] + [(n, p, c, False) for n, p in vecs]
+        off = 0
+        self.segments: List[FlatSegment] = []
+        for n, p, c, decay in ordered:
+            size = p.numel()
+            self.segments.append(FlatSegment(n, off, off + size, decay, c, p))
+            off += (size + 7) // 8 * 8     # 16-byte alignment of every tensor
+        self.numel = off
+        self.dtype, self.device = dtype, device
+        self.data = torch.zeros(off, dtype=dtype, device=device)
+        self.grad: Optional[torch.Tensor] = None
+        for seg in self.segments:
+            p = seg.param
+            view = self.data[seg.start:seg.end].view(p.shape)
+            view.copy_(p.data.to(device=device, dtype=dtype))
+            p.data = view
+
+    def ensure_grad(self):
+        if self.grad is None:
+            self.grad = torch.zeros(self.numel, dtype=self.dtype, device=self.device)
+            for seg in self.segments:
+                seg.param._mm_grad_view = self.grad[seg.start:seg.end].view(seg.param.shape)
+        return self.grad
+
+    def attach_grads(self, fresh=True):
+        """Point every trainable param's .grad at its slice of the flat buffer; `fresh` = next write overwrites."""
+        self.ensure_grad()
+        for seg in self.segments:
+            p = seg.param
+            if p.requires_grad:
+                p.grad = p._mm_grad_view
+                p._mm_fresh = fresh
+            else:
+                p.grad = None
+
+    def trainable_ranges(self) -> List[Tuple[int, int, bool]]:
+        """Maximal contiguous [start, end) ranges of trainable params with equal decay flag."""
+        out: List[List] = []
+        for seg in self.segments:
+            if not seg.param.requires_grad:
+                continue
+            end = (seg.end + 7) // 8 * 8
+            if out and out[-1][1] == seg.start and out[-1][2] == seg.decay:
+                out[-1][1] = end
+            else:
+                out.append([seg.start, end, seg.decay])
+        return [(a, min(b, self.numel), d) for a, b, d in out]

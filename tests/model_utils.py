@@ -1,0 +1,37 @@
+"""Shared helpers for model-level tests: build the product model from a golden fixture's meta + weights."""
+import json
+import os
+
+import torch
+
+from multimeditron_amd.model.model import MultimodalConfig, MultiModalModelForCausalLM
+from multimeditron_amd.model.modalities import ImageConfig
+
+
+def build_from_golden(meta, weights, tmpdir, dtype="float32", device="cuda"):
+    clip_dir = os.path.join(str(tmpdir), "clip")
+    os.makedirs(clip_dir, exist_ok=True)
+    json.dump({"vision_config": meta["vision"]}, open(os.path.join(clip_dir, "config.json"), "w"))
+    size = meta["vision"]["image_size"]
+    json.dump({"size": {"shortest_edge": size}, "crop_size": {"height": size, "width": size}},
+              open(os.path.join(clip_dir, "preprocessor_config.json"), "w"))
+    cfg = MultimodalConfig(vocab_size=meta["vocab_size"], modalities=[ImageConfig(hidden_size=meta["llm"]["hidden_size"], clip_name=clip_dir)],
+                           llm_path="unused", dtype=dtype, eos_token_idx=meta["eos_token_idx"], hidden_size=meta["llm"]["hidden_size"])
+    model = MultiModalModelForCausalLM(cfg, device=device, llm_config=meta["llm"])
+    model.load_state_dict(weights, strict=True)
+    model.pack_parameters()
+    return model
+
+
+def to_device(batch, device="cuda"):
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            out[k] = v.to(device)
+        elif k == "processed_multimodal_inputs":
+            out[k] = {"batch_idx": {t: x.to(device) for t, x in v["batch_idx"].items()},
+                      "token_range": {t: x.to(device) for t, x in v["token_range"].items()},
+                      "stacked": v["stacked"]}
+        else:
+            out[k] = v
+    return out

@@ -1,0 +1,99 @@
+"""DataCollatorForMultimodal / PromptTokenizer / image preprocessing against the outputs of the REFERENCE collator
+(tests/golden/collator.*, produced by tools/make_golden.py on mock_dataset/cat.jpg + EPFL_campus_2017.jpg).
+Integer outputs must be bit-exact; pixel tensors within 1e-6 (same PIL resize, float32 normalise)."""
+import copy
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from multimeditron_amd.dataset.loader import AutoModalityLoader, FileSystemImageLoader, RawImageLoader
+from multimeditron_amd.model.data_loader import DataCollatorForMultimodal
+from multimeditron_amd.model.model import ChatTemplate
+from multimeditron_amd.model.modalities import AutoModality, ImageConfig
+
+
+@pytest.fixture(scope="module")
+def env(golden_dir, tmp_path_factory):
+    pytest.importorskip("transformers")
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    meta = json.load(open(os.path.join(golden_dir, "collator.meta.json")))
+    vec = load_file(os.path.join(golden_dir, "collator.vectors.safetensors"))
+
+    def make_tok(side):
+        vocab = {w: i for i, w in enumerate(meta["words"])}
+        tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+        tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+        t = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|eot_id|>", unk_token="<unk>",
+                                    additional_special_tokens=["<|start_header_id|>", "<|end_header_id|>", "<|image_start|>",
+                                                               "<|image_end|>", "<|attachment|>"],
+                                    chat_template=meta["chat_template"])
+        t.pad_token = t.eos_token
+        t.padding_side = side
+        return t
+
+    d = tmp_path_factory.mktemp("clip")
+    json.dump({"vision_config": {"hidden_size": 128, "intermediate_size": 256, "num_hidden_layers": 2, "num_attention_heads": 2,
+                                 "image_size": meta["image_size"], "patch_size": meta["patch_size"]}}, open(d / "config.json", "w"))
+    json.dump({"size": {"shortest_edge": meta["image_size"]}, "crop_size": {"height": meta["image_size"], "width": meta["image_size"]}},
+              open(d / "preprocessor_config.json", "w"))
+    proc = AutoModality.preprocessor_from_name("meditron_clip", ImageConfig(hidden_size=128, clip_name=str(d)))
+    ct = ChatTemplate.llama()
+    for role in ct.delimiters:   # the synthetic whitespace tokenizer needs spaced role tags (as in make_golden.py)
+        ct.delimiters[role] = {"start": f"<|start_header_id|> {role} <|end_header_id|>", "end": "<|eot_id|>"}
+    return meta, vec, make_tok, proc, ct, os.path.join(golden_dir, "mock_dataset")
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+@pytest.mark.parametrize("gen", [False, True])
+def test_conversation_batches(env, side, gen):
+    meta, vec, make_tok, proc, ct, imgdir = env
+    coll = DataCollatorForMultimodal(tokenizer=make_tok(side), modality_processors={"image": proc},
+                                     modality_loaders={"image": AutoModalityLoader.from_name("fs-image", base_path=imgdir)},
+                                     attachment_token=meta["attachment_token"], chat_template=ct, add_generation_prompt=gen)
+    b = coll(copy.deepcopy(meta["samples_conv"]))
+    tag = f"conv_{side}_gen{int(gen)}"
+    for k in ("input_ids", "labels", "attention_mask", "position_ids"):
+        assert torch.equal(b[k], vec[f"{tag}.{k}"]), k
+    pmi = b["processed_multimodal_inputs"]
+    assert torch.equal(pmi["batch_idx"]["image"], vec[f"{tag}.batch_idx"])
+    assert torch.equal(pmi["token_range"]["image"], vec[f"{tag}.token_range"])
+    px = torch.stack(pmi["stacked"]["image"])
+    assert px.shape == vec[f"{tag}.pixels"].shape
+    assert float((px - vec[f"{tag}.pixels"]).abs().max()) < 1e-6
+    # the splice positions really hold attachment tokens
+    att = coll.tokenizer.convert_tokens_to_ids(meta["attachment_token"])
+    assert torch.all(b["input_ids"][pmi["batch_idx"]["image"], pmi["token_range"]["image"]] == att)
+
+
+def test_text_sample_raw_bytes(env):
+    meta, vec, make_tok, proc, ct, imgdir = env
+    coll = DataCollatorForMultimodal(tokenizer=make_tok("right"), modality_processors={"image": proc},
+                                     modality_loaders={"image": RawImageLoader()}, attachment_token=meta["attachment_token"],
+                                     chat_template=ct)
+    data = open(os.path.join(imgdir, "cat.jpg"), "rb").read()
+    b = coll([{"text": meta["samples_text"][0]["text"], "modalities": [{"type": "image", "value": {"bytes": data}}]}])
+    for k in ("input_ids", "labels", "attention_mask", "position_ids"):
+        assert torch.equal(b[k], vec[f"text_single.{k}"]), k
+    assert torch.equal(b["processed_multimodal_inputs"]["token_range"]["image"], vec["text_single.token_range"])
+    # ragged text batch: the reference raises inside the HF tokenizer (meta["text_branch_error"]); here it pads
+    b2 = coll([{"text": "a cat <|attachment|> sitting on grass", "modalities": [{"type": "image", "value": {"bytes": data}}]},
+               {"text": "what is this", "modalities": []}])
+    assert b2["input_ids"].shape[0] == 2 and int(b2["attention_mask"][1].sum()) == 3
+
+
+def test_errors_match_reference_behaviour(env):
+    meta, vec, make_tok, proc, ct, imgdir = env
+    coll = DataCollatorForMultimodal(tokenizer=make_tok("right"), modality_processors={"image": proc}, modality_loaders={},
+                                     attachment_token=meta["attachment_token"], chat_template=ct)
+    with pytest.raises(ValueError):      # no loader for the modality type (loader/__init__.py:73-75)
+        coll([{"text": "x <|attachment|>", "modalities": [{"type": "image", "value": "cat.jpg"}]}])
+    with pytest.raises(ValueError):      # neither text nor conversations (prompt_tokenizers.py:74-77)
+        coll([{"modalities": []}])
+    with pytest.raises(FileNotFoundError):
+        FileSystemImageLoader(imgdir).load({"value": "missing.jpg"})
+    with pytest.raises(ValueError):
+        ChatTemplate.from_name("nope")

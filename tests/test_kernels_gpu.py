@@ -49,7 +49,8 @@ def test_lane_maps(K):
             fa[l, j] = A[l & 31, 8 * (l >> 5) + j]
             fb[l, j] = B[8 * (l >> 5) + j, l & 31]
     out = torch.empty(64, 16, device="cuda")
-    call("mm_debug_mfma", 32, fa.bfloat16().cuda().data_ptr(), fb.bfloat16().cuda().data_ptr(), out.data_ptr(), 0)
+    fa_d, fb_d = fa.bfloat16().cuda(), fb.bfloat16().cuda()   # keep alive: raw pointers cross the ABI
+    call("mm_debug_mfma", 32, fa_d.data_ptr(), fb_d.data_ptr(), out.data_ptr(), 0)
     torch.cuda.synchronize()
     C = A @ B
     got = torch.empty(32, 32)
@@ -66,7 +67,8 @@ def test_lane_maps(K):
             fa[l, j] = A[l & 15, 8 * (l >> 4) + j]
             fb[l, j] = B[8 * (l >> 4) + j, l & 15]
     out = torch.empty(64, 4, device="cuda")
-    call("mm_debug_mfma", 16, fa.bfloat16().cuda().data_ptr(), fb.bfloat16().cuda().data_ptr(), out.data_ptr(), 0)
+    fa_d, fb_d = fa.bfloat16().cuda(), fb.bfloat16().cuda()
+    call("mm_debug_mfma", 16, fa_d.data_ptr(), fb_d.data_ptr(), out.data_ptr(), 0)
     torch.cuda.synchronize()
     C = A @ B
     got = torch.empty(16, 16)
@@ -85,7 +87,8 @@ def test_lane_maps(K):
         q, p = i >> 2, i & 3
         addr[l] = ((r0[grp] + q) * 64 + c0[grp] + 4 * p) * 2
     out = torch.empty(256, dtype=torch.bfloat16, device="cuda")
-    call("mm_debug_tr_read", img.bfloat16().cuda().data_ptr(), addr.cuda().data_ptr(), out.data_ptr(), 0)
+    img_d, addr_d = img.bfloat16().cuda(), addr.cuda()
+    call("mm_debug_tr_read", img_d.data_ptr(), addr_d.data_ptr(), out.data_ptr(), 0)
     torch.cuda.synchronize()
     o = out.float().cpu().reshape(64, 4)
     for l in range(64):
@@ -212,7 +215,7 @@ def test_attention_fwd_bwd(K, dtype, case):
         if B > 1:
             mask[1, Skv - 5:] = 0        # right padding on sample 1
     scale = D ** -0.5
-    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
     ref = attn_ref(qf, kf, vf, mask, causal, scale)
     ref.backward(do.float())
     if Sq == Skv:
@@ -257,7 +260,7 @@ def test_norms(K, dtype, H):
     w = w.to(dtype)
     tol = TOL[dtype]
     # RMSNorm
-    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    xf, wf = x.float().clone().requires_grad_(True), w.float().clone().requires_grad_(True)
     ref = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5))
     ref.backward(dy.float())
     y, rstd = K.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-5)
@@ -268,7 +271,7 @@ def test_norms(K, dtype, H):
     assert rel(dx.float(), xf.grad) < tol * 2
     assert rel(dw.float(), wf.grad) < tol * 2
     # LayerNorm
-    xf, wf, bf = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    xf, wf, bf = (t.float().clone().requires_grad_(True) for t in (x, w, b))
     ref = F.layer_norm(xf, (H,), wf, bf, 1e-5)
     ref.backward(dy.float())
     y, mean, rstd = K.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), 1e-5)
@@ -315,7 +318,7 @@ def test_rope(K, dtype, D):
 def test_activations(K, dtype):
     M, I = 33, 256
     gu, dout = rnd((M, 2 * I), dtype, 41), rnd((M, I), dtype, 42)
-    guf = gu.float().requires_grad_(True)
+    guf = gu.float().clone().requires_grad_(True)
     ref = F.silu(guf[:, :I]) * guf[:, I:]
     ref.backward(dout.float())
     tol = TOL[dtype]
@@ -323,7 +326,7 @@ def test_activations(K, dtype):
     assert rel(K.swiglu_bwd(gu.cuda(), dout.cuda(), I).float(), guf.grad) < tol * 2
     x, dy = rnd((1000 + 3,), dtype, 43, 2.0), rnd((1000 + 3,), dtype, 44)
     for kind, fn in [(0, F.gelu), (1, lambda t: t * torch.sigmoid(1.702 * t))]:
-        xf = x.float().requires_grad_(True)
+        xf = x.float().clone().requires_grad_(True)
         r = fn(xf)
         r.backward(dy.float())
         assert rel(K.gelu_fwd(x.cuda(), kind).float(), r.detach()) < tol
@@ -339,7 +342,7 @@ def test_cross_entropy(K, dtype, V):
     logits = rnd((T, V), dtype, 51, 2.0)
     labels = torch.randint(0, V, (T,), generator=torch.Generator().manual_seed(52))
     labels[::4] = -100
-    lf = logits.float().requires_grad_(True)
+    lf = logits.float().clone().requires_grad_(True)
     ref = F.cross_entropy(lf, labels, ignore_index=-100)
     ref.backward()
     buf = torch.zeros(T, ld, dtype=dtype, device="cuda")
@@ -375,8 +378,8 @@ def test_embed_splice(K, dtype):
     assert torch.equal(out2.float().cpu(), e.reshape(B * S, H))
     # backward
     dE = rnd((B * S, H), dtype, 64)
-    ef = emb.float().requires_grad_(True)
-    pf = proj.float().requires_grad_(True)
+    ef = emb.float().clone().requires_grad_(True)
+    pf = proj.float().clone().requires_grad_(True)
     r = F.embedding(ids, ef).clone()
     r[bi, tr] = pf
     r.reshape(B * S, H).backward(dE.float())
