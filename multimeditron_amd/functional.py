@@ -27,6 +27,9 @@ def grad_target(p: torch.Tensor):
     """-> (grad buffer, accumulate?) for writing p's gradient in place."""
     if p.grad is None:
         view = getattr(p, "_mm_grad_view", None)
+        if view is None and getattr(p, "_mm_flat", None) is not None:
+            p._mm_flat.ensure_grad()          # packed model: gradients live in the flat buffer (fused groups need it)
+            view = p._mm_grad_view
         p.grad = view if view is not None else torch.empty_like(p)
         fresh = True
     else:
@@ -52,9 +55,12 @@ class ParamGroup:
         if len(ts) == 1:
             return ts[0]
         first = ts[0]
+        if any(t is None for t in ts):
+            return None
         ptr = first.data_ptr()
+        base = first.untyped_storage().data_ptr()
         for t in ts:
-            if t.data_ptr() != ptr or not t.is_contiguous():
+            if t.data_ptr() != ptr or not t.is_contiguous() or t.untyped_storage().data_ptr() != base:
                 return None
             ptr += t.numel() * t.element_size()
         rows = sum(t.shape[0] for t in ts)

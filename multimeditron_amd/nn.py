@@ -114,6 +114,8 @@ class FlatParams:
             view = self.data[seg.start:seg.end].view(p.shape)
             view.copy_(p.data.to(device=device, dtype=dtype))
             p.data = view
+            p._mm_flat = self
+            p._mm_grad_view = None
 
     def ensure_grad(self):
         if self.grad is None:

@@ -1,0 +1,159 @@
+"""Data-parallel training step for the multimodal hot path: the MI355X replacement for the reference's
+`MultimodalTrainer(transformers.Trainer)` + DeepSpeed ZeRO-3 (train/trainer.py:16-198, config/deepspeed.json).
+
+What is kept from the reference: `TrainingMode` and its freeze policies (trainer.py:16-23,132-144), `compute_loss`
+(trainer.py:91-118: loss = mean CE over the non-ignored tokens of the micro-batch), the optimiser recipe of
+config/config_alignment.yaml:38-59 (AdamW lr 1e-4, wd 0.01, clip 1.0, cosine_with_min_lr, gradient accumulation).
+
+What is redesigned for MI355X: parameters / AdamW state are REPLICATED (8.35 B x 14 B = 117 GB fits 288 GB HBM3E, so
+no ZeRO sharding, no CPU offload); one process per GPU; gradients live in one flat bf16 buffer cut into buckets;
+each bucket's all-reduce (RCCL, `torch.distributed` backend "nccl", which runs it on its own HIP stream) is launched
+from the backward pass as soon as the last wgrad of that bucket has been enqueued, so the exchange overlaps the rest
+of backward (decoder layers first, vision tower last); the global grad-norm, clipping and AdamW are three fused
+HBM-bound kernels over the flat buffers with no host synchronisation."""
+from __future__ import annotations
+
+import math
+from enum import IntEnum
+from typing import Any, Dict, Iterable, List, Optional
+
+import torch
+
+from .. import functional as Fm
+from .. import kernels as K
+from .exchange import GradExchanger
+
+
+class TrainingMode(IntEnum):
+    ALIGNMENT = 0
+    END2END = 1
+    LM_ONLY = 2
+    FULL = 3
+
+
+TRAINING_MAPPING = {i.name: i for i in TrainingMode}
+
+
+def cosine_with_min_lr(step: int, total: int, base_lr: float, min_lr: float, warmup: int = 0) -> float:
+    if total <= 0:
+        return base_lr
+    if step < warmup:
+        return base_lr * (step + 1) / max(1, warmup)
+    prog = min(1.0, (step - warmup) / max(1, total - warmup))
+    return min_lr + (base_lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * prog))
+
+
+class MultimodalTrainer:
+    def __init__(self, model, training_mode: TrainingMode = TrainingMode.ALIGNMENT, learning_rate: float = 1e-4,
+                 weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 1.0,
+                 gradient_accumulation_steps: int = 1, max_steps: int = 0, min_lr: Optional[float] = None, warmup_steps: int = 0,
+                 bucket_mb: int = 256, process_group=None, data_collator=None, train_dataset=None):
+        self.model = model
+        self.training_mode = TrainingMode(training_mode)
+        self.lr, self.wd, self.betas, self.eps = learning_rate, weight_decay, betas, eps
+        self.max_grad_norm = max_grad_norm
+        self.accum = max(1, gradient_accumulation_steps)
+        self.max_steps, self.min_lr, self.warmup = max_steps, (min_lr if min_lr is not None else learning_rate), warmup_steps
+        self.data_collator, self.train_dataset = data_collator, train_dataset
+        self.step_count = 0
+        self._micro = 0
+        import torch.distributed as dist
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.pg = process_group
+        self.world = self.dist.get_world_size(self.pg) if self.dist else 1
+        self.bucket_elems = bucket_mb * 1024 * 1024 // 2
+        self._set_mode()
+        self._setup_state()
+
+    # ------------------------------------------------------------------ setup
+    def _set_mode(self):
+        m = self.model
+        m.train()
+        {TrainingMode.ALIGNMENT: m.freeze_for_alignment, TrainingMode.LM_ONLY: m.freeze_for_lm,
+         TrainingMode.END2END: m.freeze_for_end2end, TrainingMode.FULL: m.unfreeze}[self.training_mode]()
+
+    def _setup_state(self):
+        flat = self.model.flat_params()
+        flat.ensure_grad()
+        self.flat = flat
+        self.ranges = flat.trainable_ranges()            # [(start, end, decay)]
+        if not self.ranges:
+            raise ValueError("no trainable parameters in this training mode")
+        n_train = sum(e - s for s, e, _ in self.ranges)
+        dev = flat.device
+        # optimizer state only for the trainable ranges, packed back to back
+        self.master = torch.empty(n_train, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n_train, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n_train, dtype=torch.float32, device=dev)
+        off = 0
+        self.state_off = []
+        for s, e, _ in self.ranges:
+            self.master[off:off + e - s].copy_(flat.data[s:e])          # device copy of the bf16 weights (plumbing)
+            self.state_off.append(off)
+            off += e - s
+        segs = [(id(seg.param), seg.start, seg.end) for seg in flat.segments if seg.param.requires_grad]
+        self._trainable = [seg for seg in flat.segments if seg.param.requires_grad]
+        self.exchanger = GradExchanger(flat.grad, [(s, e) for s, e, _ in self.ranges], segs, self.bucket_elems,
+                                       dist=self.dist if self.world > 1 else None, group=self.pg)
+
+    # ------------------------------------------------------------------ reference surface
+    def compute_loss(self, model, inputs, return_outputs=False, **kwargs):
+        """reference trainer.py:91-118"""
+        outputs = model(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"), labels=inputs["labels"],
+                        position_ids=inputs["position_ids"], processed_multimodal_inputs=inputs["processed_multimodal_inputs"])
+        return (outputs.loss, outputs) if return_outputs else outputs.loss
+
+    # ------------------------------------------------------------------ one optimisation step
+    def training_step(self, inputs: Dict[str, Any]) -> torch.Tensor:
+        """forward + backward of one micro-batch; on the accumulation boundary also exchange, clip and AdamW.
+        Returns the (detached, device) micro-batch loss."""
+        first = self._micro == 0
+        last = self._micro == self.accum - 1
+        if first:
+            self.flat.attach_grads(fresh=True)       # no memset: the first wgrad of the step overwrites
+        ex = self.exchanger
+        ex.begin_step(exchange_this_step=last)
+        Fm.set_grad_ready_hook(lambda p: ex.on_ready(id(p)))
+        try:
+            loss = self.compute_loss(self.model, inputs)
+            # mean over micro-batches and ranks (HF Trainer with model_accepts_loss_kwargs=False, trainer.py:80)
+            loss.backward(gradient=torch.full_like(loss, 1.0 / (self.accum * self.world)))
+        finally:
+            Fm.set_grad_ready_hook(None)
+        self._micro += 1
+        if last:
+            # a parameter nothing wrote to this step (e.g. the vision tower on a text-only batch) still holds the previous
+            # step's values because nothing memsets the flat buffer: zero exactly those slices
+            for seg in self._trainable:
+                if getattr(seg.param, "_mm_fresh", False):
+                    self.flat.grad[seg.start:seg.end].zero_()
+                    seg.param._mm_fresh = False
+            ex.finish_step()
+            self._optimizer_step()
+            self._micro = 0
+        else:
+            ex.finish_step()
+        return loss.detach()
+
+    def _optimizer_step(self):
+        self.step_count += 1
+        lr = cosine_with_min_lr(self.step_count - 1, self.max_steps, self.lr, self.min_lr, self.warmup)
+        g = self.flat.grad
+        total = K.gradnorm([g[s:e] for s, e, _ in self.ranges], self.max_grad_norm if self.max_grad_norm else 0.0)
+        self.last_grad_norm = total
+        for (s, e, decay), off in zip(self.ranges, self.state_off):
+            n = e - s
+            K.adamw_step(self.flat.data[s:e], g[s:e], self.master[off:off + n], self.m[off:off + n], self.v[off:off + n], lr,
+                         self.betas[0], self.betas[1], self.eps, self.wd if decay else 0.0, self.step_count, clip=total)
+
+    def train(self, batches: Optional[Iterable[Dict[str, Any]]] = None, max_steps: Optional[int] = None):
+        """Minimal loop: iterate collated batches (or collate `train_dataset` with `data_collator` in fixed-size chunks)."""
+        losses = []
+        steps = max_steps or self.max_steps or 0
+        for i, batch in enumerate(batches):
+            losses.append(self.training_step(batch))
+            if steps and (i + 1) >= steps * self.accum:
+                break
+        if self.dist is not None:
+            self.dist.barrier(group=self.pg)       # reference cli/train.py:200-201
+        return losses

@@ -78,7 +78,7 @@ def test_lane_maps(K):
             got[4 * (l >> 4) + r, l & 15] = o[l, r]
     assert torch.equal(got, C), "16x16x32 C/D or A/B lane map"
     # --- ds_read_b64_tr_b16: image [64 rows][64 cols] bf16 (128-B rows); each 16-lane group reads a 4x16 block
-    img = torch.arange(4096).reshape(64, 64) % 509
+    img = torch.arange(4096).reshape(64, 64) % 251   # exact in bf16
     addr = torch.empty(64, dtype=torch.int32)
     r0 = [0, 8, 20, 36]   # block first row per group
     c0 = [0, 16, 32, 48]  # block first column per group
