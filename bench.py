@@ -101,7 +101,7 @@ def measure_gemm_roofline(trainer, batch):
                 achieved_tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0, gemm_ms_per_step=tot_ms)
 
 
-def cpu_baseline(llm, vis, hidden, budget_layers=2, S=512):
+def cpu_baseline(llm, vis, hidden, workload, budget_layers=4, S=1024, B=2):
     """The CPU oracle (torch CPU ops, the restatement of the reference's HF path) on a bounded slice of the workload:
     the 8B-shaped decoder truncated to `budget_layers` layers + ViT truncated likewise + projector + full lm_head, B=1,
     fwd+bwd in bf16 (the reference trains under torch.set_default_dtype(bfloat16)); converted to equivalent samples/s of the
@@ -148,19 +148,20 @@ def cpu_baseline(llm, vis, hidden, budget_layers=2, S=512):
     pp = R.PROJ_PREFIX
     mk(pp + "0.weight", Dv, Dv); mk(pp + "0.bias", Dv); mk(pp + "2.weight", hidden, Dv); mk(pp + "2.bias", hidden)
     mk(pp + "4.weight", hidden, hidden); mk(pp + "4.bias", hidden)
-    b, _ = synthetic_batch(1, S, 1, P, vocab, (128256, 128257, 128002), 11, "cpu", vis["image_size"])
-    b["attention_mask"] = torch.ones(1, S, dtype=torch.long)
+    b, _ = synthetic_batch(B, S, 1, P, vocab, (128256, 128257, 128002), 11, "cpu", vis["image_size"])
+    b["attention_mask"] = torch.ones(B, S, dtype=torch.long)
     pm = b["processed_multimodal_inputs"]
     pm["stacked"]["image"] = [x.to(dt) for x in pm["stacked"]["image"]]
     meta = {"vision": vis_s, "llm": llm_s, "eos_token_idx": 0}
-    fl = 3.0 * flops_per_sample(llm_s, vis_s, S, 1, vocab, hidden)
+    fl = 3.0 * B * flops_per_sample(llm_s, vis_s, S, 1, vocab, hidden)
     t0 = time.time()
     _, loss = R.multimodal_forward(w, b, meta)
     loss.backward()
     dtm = time.time() - t0
     return dict(seconds=dtm, flops=fl, cores=cores,
-                sample=f"oracle/ref_cpu.py fwd+bwd bf16, B=1 S={S}, {budget_layers}-layer slice of the 8B decoder + {budget_layers}-layer "
-                       f"ViT-L/14 + projector + full lm_head; scaled to the full workload by algorithmic FLOPs")
+                sample=f"oracle/ref_cpu.py fwd+bwd bf16, B={B} S={S}, {budget_layers}-layer slice of the {workload} decoder + "
+                       f"{budget_layers}-layer slice of its ViT + projector + full lm_head (vocab 128258); converted to samples/s of the "
+                       f"full workload by algorithmic FLOPs")
 
 
 def main():
@@ -246,7 +247,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del trainer, model, batch
             torch.cuda.empty_cache()
-            c = cpu_baseline(llm, vis, llm["hidden_size"])
+            c = cpu_baseline(llm, vis, llm["hidden_size"], args.workload)
             full = 3.0 * flops_per_sample(llm, vis, S, n_img, vocab, llm["hidden_size"])
             out["cpu_baseline"] = {"value": round(c["flops"] / c["seconds"] / full, 6), "unit": "samples/s", "cores": c["cores"], "kind": "port",
                                    "sample": c["sample"], "measured_seconds": round(c["seconds"], 2),

@@ -117,7 +117,8 @@ class MultimodalTrainer:
         try:
             loss = self.compute_loss(self.model, inputs)
             # mean over micro-batches and ranks (HF Trainer with model_accepts_loss_kwargs=False, trainer.py:80)
-            loss.backward(gradient=torch.full_like(loss, 1.0 / (self.accum * self.world)))
+            if loss.requires_grad:      # e.g. ALIGNMENT mode on a text-only micro-batch: nothing trainable is on the path
+                loss.backward(gradient=torch.full_like(loss, 1.0 / (self.accum * self.world)))
         finally:
             Fm.set_grad_ready_hook(None)
         self._micro += 1
