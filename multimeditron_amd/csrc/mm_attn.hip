@@ -450,58 +450,62 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
   int qt0 = 0;
   if (a.causal) qt0 = max(0, (int)blockIdx.x * 128 - shift) / BQ;
   const int nqt = (a.Sq + BQ - 1) / BQ;
-  KcStage<D, BQ> qcs, ocs;  // NI = D/64 registers each; each tile is written to both images
-  for (int g = 0; g < G; ++g) {
+  const int per_head = max(0, nqt - qt0);
+  const int niter = per_head * G;                  // (q head in group) x (query tile), flattened for prefetching
+  const int64_t do_ss = (int64_t)a.Hq * D;
+  KcStage<D, BQ> qcs, ocs;                         // each tile is written to both LDS images
+  float rc = 0.f;
+  auto prefetch = [&](int it) {
+    const int g = it / per_head, qb = (qt0 + it % per_head) * BQ;
     const int hq = hkv * G + g;
     const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
     const bf16* dO = (const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * D;
-    const int64_t do_ss = (int64_t)a.Hq * D;
-    const float* lse = a.lse + ((int64_t)b * a.Hq + hq) * a.Sq;
-    const float* dlt = a.delta + ((int64_t)b * a.Hq + hq) * a.Sq;
-    for (int qt = qt0; qt < nqt; ++qt) {
-      const int qb = qt * BQ;
-      qcs.load(Q, a.q_ss, qb, a.Sq);
-      ocs.load(dO, do_ss, qb, a.Sq);
-      float rc = 0.f;
-      if (threadIdx.x < 64) {
-        const int qq = qb + (threadIdx.x & 31);
-        if (threadIdx.x < 32) rc = qq < a.Sq ? lse[qq] * LOG2E : INFINITY;
-        else rc = qq < a.Sq ? dlt[qq] : 0.f;
-      }
-      __syncthreads();  // previous tile fully consumed
-      qcs.store(Qc);
-      qcs.store_rowmajor(Qr);
-      ocs.store(Oc);
-      ocs.store_rowmajor(Or);
-      if (threadIdx.x < 64) rowc[threadIdx.x] = rc;
-      __syncthreads();
-      f32x16 s_acc, dp_acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
-#pragma unroll
-      for (int ds = 0; ds < NDS; ++ds) {
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BQ>(Qc, 0, ds), kf[ds], s_acc, 0, 0, 0);
-        dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BQ>(Oc, 0, ds), vf[ds], dp_acc, 0, 0, 0);
-      }
-      bf16x8 pf[2], dsf[2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = acc_row(r, h);
-        bool ok = kvalid;
-        if (a.causal) ok = ok && ki <= (qb + ql + shift);
-        const float p = ok ? exp2f(s_acc[r] * sc - rowc[ql]) : 0.f;
-        const float dsv = p * (dp_acc[r] - rowc[32 + ql]) * a.scale;
-        pf[r >> 3][r & 7] = (bf16)p;
-        dsf[r >> 3][r & 7] = (bf16)dsv;
-      }
-#pragma unroll
-      for (int db = 0; db < NDB; ++db)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks_frag_t<D>(Or, db, s * 16), pf[s], dv_acc[db], 0, 0, 0);
-          dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks_frag_t<D>(Qr, db, s * 16), dsf[s], dk_acc[db], 0, 0, 0);
-        }
+    qcs.load(Q, a.q_ss, qb, a.Sq);
+    ocs.load(dO, do_ss, qb, a.Sq);
+    if (threadIdx.x < 64) {
+      const int qq = qb + (threadIdx.x & 31);
+      const int64_t ro = ((int64_t)b * a.Hq + hq) * a.Sq + qq;
+      if (threadIdx.x < 32) rc = qq < a.Sq ? a.lse[ro] * LOG2E : INFINITY;
+      else rc = qq < a.Sq ? a.delta[ro] : 0.f;
     }
+  };
+  if (niter > 0) prefetch(0);
+  for (int it = 0; it < niter; ++it) {
+    const int qb = (qt0 + it % per_head) * BQ;
+    __syncthreads();  // previous tile fully consumed
+    qcs.store(Qc);
+    qcs.store_rowmajor(Qr);
+    ocs.store(Oc);
+    ocs.store_rowmajor(Or);
+    if (threadIdx.x < 64) rowc[threadIdx.x] = rc;
+    __syncthreads();
+    if (it + 1 < niter) prefetch(it + 1);
+    f32x16 s_acc, dp_acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+      s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BQ>(Qc, 0, ds), kf[ds], s_acc, 0, 0, 0);
+      dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BQ>(Oc, 0, ds), vf[ds], dp_acc, 0, 0, 0);
+    }
+    bf16x8 pf[2], dsf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = acc_row(r, h);
+      bool ok = kvalid;
+      if (a.causal) ok = ok && ki <= (qb + ql + shift);
+      const float p = ok ? exp2f(s_acc[r] * sc - rowc[ql]) : 0.f;
+      const float dsv = p * (dp_acc[r] - rowc[32 + ql]) * a.scale;
+      pf[r >> 3][r & 7] = (bf16)p;
+      dsf[r >> 3][r & 7] = (bf16)dsv;
+    }
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks_frag_t<D>(Or, db, s * 16), pf[s], dv_acc[db], 0, 0, 0);
+        dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks_frag_t<D>(Qr, db, s * 16), dsf[s], dk_acc[db], 0, 0, 0);
+      }
   }
   if (ki < a.Skv) {
     bf16* dkrow = (bf16*)a.dk + b * a.k_sb + hkv * a.k_sh + (int64_t)ki * a.k_ss;

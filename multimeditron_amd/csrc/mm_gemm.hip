@@ -4,7 +4,7 @@
 // v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Operands are staged HBM -> registers -> LDS with
 // 16-byte accesses and one barrier per K-step (double-buffered LDS, next tile's global loads issued
 // before the current tile's MFMAs).  Two LDS images, chosen per operand by how it lies in memory:
-//   KC (K contiguous, global [X][K])  image [k/8][x][8]      fragments by ds_read_b128 (conflict free)
+//   KC (K contiguous, global [X][K])  image [x][k] swizzled  fragments by ds_read_b128 (conflict free)
 //   KS (K strided,    global [K][X])  image [k][x] swizzled  fragments by 2x ds_read_b64_tr_b16
 // so NT / NN / TN need no transposed copy of any tensor.  The MFMA is issued with swapped operands
 // (D^T = B^T A^T) so each lane owns 4 consecutive output columns -> 8-byte stores, and bias /
@@ -56,6 +56,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, in
 }
 
 __device__ __forceinline__ int ks_swz(int k) { return (k & 3) | ((k >> 1) & 4); }
+// KC image = row-major [x][64 k] (128-B rows), 16-B chunk index XOR (row>>1)&7: ds_write_b128 of one row (8 lanes) and
+// ds_read_b128 of 16 rows at one/two chunk columns are both bank-conflict free
+__device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
@@ -68,7 +71,7 @@ __device__ __forceinline__ void stage_load(u32x4 (&r)[4], const bf16* base, int 
   if constexpr (KC) {
     const bf16* b = base + (int64_t)x0 * ld + k0;
     auto rs = make_rsrc(b, ((int64_t)(Xtot - x0) * ld - k0) * 2);
-    const int r_in = l & 7, kc = l >> 3;
+    const int kc = l & 7, r_in = l >> 3;   // 8 adjacent lanes = one full 128-B line of a row
     const bool kok = (k0 + kc * 8) < Ktot;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -94,11 +97,11 @@ template <bool KC>
 __device__ __forceinline__ void stage_store(const u32x4 (&r)[4], char* tile) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   if constexpr (KC) {
-    const int r_in = l & 7, kc = l >> 3;
+    const int kc = l & 7, r_in = l >> 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (w * 4 + i) * 8 + r_in;
-      *(u32x4*)(tile + (kc * 128 + row) * 16) = r[i];
+      *(u32x4*)(tile + row * 128 + ((kc ^ kc_swz(row)) * 16)) = r[i];
     }
   } else {
     const int xc = l & 15, kr = l >> 4;
@@ -116,7 +119,8 @@ template <bool KC>
 __device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
   const int l = threadIdx.x & 63;
   if constexpr (KC) {
-    return *(const bf16x8*)(tile + ((ks * 4 + (l >> 4)) * 128 + xb * 16 + (l & 15)) * 16);
+    const int row = xb * 16 + (l & 15), kc = ks * 4 + (l >> 4);
+    return *(const bf16x8*)(tile + row * 128 + ((kc ^ kc_swz(row)) * 16));
   } else {
     const int g = l >> 4, i = l & 15, q = i >> 2, p = i & 3;
     const int k = ks * 32 + 8 * g + q;

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Attention micro-benchmark at the 8B step's shape (B=4,S=2048,Hq=32,Hkv=8,D=128 causal) + ViT shape."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimeditron_amd import kernels as K
+
+
+def run(B, S, Hq, Hkv, D, causal):
+    W = (Hq + 2 * Hkv) * D
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(B * S, W, device="cuda", generator=g).to(torch.bfloat16)
+    q = qkv[:, : Hq * D].view(B, S, Hq, D); k = qkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D); v = qkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+    dqkv = torch.empty_like(qkv)
+    dq = dqkv[:, : Hq * D].view(B, S, Hq, D); dk = dqkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D); dv = dqkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+    do = torch.randn(B, S, Hq, D, device="cuda", generator=g).to(torch.bfloat16)
+    sc = D ** -0.5
+    out, lse = K.attn_fwd(q, k, v, None, causal, sc)
+    K.attn_bwd(q, k, v, out, do, lse, None, causal, sc, dq, dk, dv)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    it = 5
+    ev[0].record()
+    for _ in range(it):
+        out, lse = K.attn_fwd(q, k, v, None, causal, sc)
+    ev[1].record()
+    for _ in range(it):
+        K.attn_bwd(q, k, v, out, do, lse, None, causal, sc, dq, dk, dv)
+    ev[2].record()
+    torch.cuda.synchronize()
+    f = 4.0 * B * Hq * S * S * D * (0.5 if causal else 1.0)
+    tf, tb = ev[0].elapsed_time(ev[1]) / it, ev[1].elapsed_time(ev[2]) / it
+    print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} D={D} causal={causal}: fwd {tf:.3f} ms ({f / tf / 1e9:.0f} TF/s)  bwd {tb:.3f} ms ({2.5 * f / tb / 1e9:.0f} TF/s algorithmic)", flush=True)
+
+
+run(4, 2048, 32, 8, 128, True)
+run(4, 257, 16, 16, 64, False)
+run(2, 4096, 32, 8, 128, True)

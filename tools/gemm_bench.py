@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""GEMM micro-benchmark on the shapes of the 8B training step (run on the GPU box).
+   python tools/gemm_bench.py [--quick]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimeditron_amd import kernels as K
+
+T = 8192
+SHAPES = {
+    "NT": [(T, 6144, 4096), (T, 4096, 4096), (T, 28672, 4096), (T, 4096, 14336), (T, 128258, 4096)],
+    "NN": [(T, 4096, 6144), (T, 4096, 4096), (T, 4096, 28672), (T, 14336, 4096), (T, 4096, 128258)],
+    "TN": [(6144, 4096, T), (4096, 4096, T), (28672, 4096, T), (4096, 14336, T), (128258, 4096, T)],
+}
+LAY = {"NT": 0, "NN": 1, "TN": 2}
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def operands(lay, M, N, Kd):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    r = lambda *s: (torch.rand(*s, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
+    if lay == "NT":
+        return r(M, Kd)[:, :Kd], r(N, Kd)
+    if lay == "NN":
+        a = torch.zeros(M, pad64(Kd), device="cuda", dtype=torch.bfloat16); a[:, :Kd] = r(M, Kd)
+        return a[:, :Kd], r(Kd, N)
+    a = torch.zeros(Kd, pad64(M), device="cuda", dtype=torch.bfloat16); a[:, :M] = r(Kd, M)
+    return a[:, :M], r(Kd, N)
+
+
+def main():
+    quick = "--quick" in sys.argv
+    tot_f = tot_t = 0.0
+    for lay, shapes in SHAPES.items():
+        for (M, N, Kd) in (shapes[:2] if quick else shapes):
+            a, b = operands(lay, M, N, Kd)
+            c = torch.empty(M, pad64(N), device="cuda", dtype=torch.bfloat16)[:, :N]
+            for _ in range(2):
+                K.gemm(LAY[lay], a, b, M, N, Kd, out=c)
+            torch.cuda.synchronize()
+            it = 5
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(it):
+                K.gemm(LAY[lay], a, b, M, N, Kd, out=c)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / it
+            fl = 2.0 * M * N * Kd
+            tot_f += fl; tot_t += ms
+            print(f"{lay} M={M:6d} N={N:6d} K={Kd:6d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TF/s", flush=True)
+    print(f"TOTAL {tot_t:.2f} ms  {tot_f / tot_t / 1e9:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
