@@ -15,6 +15,8 @@
 // A/B panels its concurrent workgroups share.
 //
 // f32 path (parity only): 64x64x16 tiles on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+#include <stdlib.h>
+
 #include "mm_common.h"
 
 namespace {
@@ -134,6 +136,70 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
   }
 }
 
+// epilogue shared by the bf16 kernels: acc[i][j][r] = C[mw + i*16 + (l&15)][nw + j*16 + 4*(l>>4) + r]
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw) {
+  const int l = threadIdx.x & 63;
+  bf16* C = (bf16*)g.C;
+  const bf16* bias = (const bf16*)g.bias;
+  const bf16* R = (const bf16*)g.residual;
+  const int epi = g.epi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mw + i * 16 + (l & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nw + j * 16 + 4 * (l >> 4);
+      if (n >= g.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const bool full = (n + 3) < g.N;
+      bf16* cp = C + (int64_t)m * g.ldc + n;
+      if (epi & MM_EPI_BIAS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (full || n + r < g.N) v[r] += (float)bias[n + r];
+      }
+      if (epi & MM_EPI_GELU_ERF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_gelu_erf(v[r]);
+      } else if (epi & MM_EPI_QUICK_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_quick_gelu(v[r]);
+      }
+      if (epi & MM_EPI_RESIDUAL) {
+        const bf16* rp = R + (int64_t)m * g.ldr + n;
+        if (full) {
+          bf16x4 rv = *(const bf16x4*)rp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < g.N) v[r] += (float)rp[r];
+        }
+      }
+      if (epi & MM_EPI_ACCUMULATE) {
+        if (full) {
+          bf16x4 cv = *(const bf16x4*)cp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)cv[r];
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < g.N) v[r] += (float)cp[r];
+        }
+      }
+      if (full) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+        *(bf16x4*)cp = o;
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < g.N) cp[r] = (bf16)v[r];
+      }
+    }
+  }
+}
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
@@ -187,66 +253,184 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + (l&15)][n0 + wn*64 + j*16 + 4*(l>>4) + r]
-  bf16* C = (bf16*)g.C;
-  const bf16* bias = (const bf16*)g.bias;
-  const bf16* R = (const bf16*)g.residual;
-  const int epi = g.epi;
+  gemm_epilogue(g, acc, m0 + wm * 64, n0 + wn * 64);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// v2 main kernel: 256x128x64 tile, 8 waves (4 along M x 2 along N, 64x64 each), operands streamed HBM -> LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write, hardware bounds check) into a 3-deep
+// ring; ONE raw s_barrier per K-tile and a counted s_waitcnt vmcnt(6) that leaves the next tile's six DMAs in
+// flight across the barrier (the DMA of tile t+2 is issued right after the barrier that retires tile t-1's reads).
+// LDS images are identical to v1 (swizzle applied on the per-lane SOURCE address, destination linear in lane
+// order as LDS-DMA requires), so fragment reads stay bank-conflict free.
+// ------------------------------------------------------------------------------------------------------
+constexpr int G_BM = 256, G_BN = 128, G_BK = 64, G_STAGES = 3;
+constexpr int G_A_BYTES = G_BM * G_BK * 2, G_B_BYTES = G_BN * G_BK * 2, G_STAGE_BYTES = G_A_BYTES + G_B_BYTES;
+
+// LDS-DMA issued from inline asm so that hipcc's waitcnt pass does not know about it: with the builtin form the
+// compiler drains vmcnt(0) in front of every ds_read_b64_tr_b16 (it cannot disprove aliasing), which serialises the
+// ring.  Completion is tracked by hand (counted s_waitcnt vmcnt + s_barrier in the K loop).  The descriptor words are
+// forced into SGPRs with readfirstlane (they are wave-uniform by construction); M0 (LDS destination) is saved/restored.
+struct SRsrc { unsigned w0, w1, w2, w3; };
+__device__ __forceinline__ SRsrc make_srsrc(const void* base, int64_t bytes) {
+  if (bytes < 0) bytes = 0;
+  const unsigned nb = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes;
+  const uint64_t a = (uint64_t)base;
+  SRsrc r;
+  r.w0 = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.w1 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  r.w2 = __builtin_amdgcn_readfirstlane(nb);
+  r.w3 = 0x00020000u;
+  return r;
+}
+// N LDS-DMA pieces of one operand tile in ONE asm statement: M0 saved/restored once, one hazard pad for the
+// freshly written descriptor SGPRs (the compiler pads nothing inside an asm string).
+template <int N>
+__device__ __forceinline__ void lds_dma16xN(const SRsrc& r, const unsigned (&voff)[N], unsigned lds_addr0) {
+  static_assert(N == 2 || N == 4, "pieces per wave");
+  u32x4 d = {r.w0, r.w1, r.w2, r.w3};
+  unsigned keep;
+  if constexpr (N == 4) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "buffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "buffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "buffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(lds_addr0), "s"(d)
+        : "memory", "scc");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "buffer_load_dwordx4 %2, %4, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "s"(lds_addr0), "s"(d)
+        : "memory", "scc");
+  }
+}
+
+// issue the LDS-DMA of one operand tile ([XR rows/cols] x 64 k) into `tile`; every wave moves XR/64 1-KiB pieces
+// descriptor of one operand anchored at the tile origin (k = 0); built once per workgroup
+template <bool KC>
+__device__ __forceinline__ SRsrc tile_rsrc(const bf16* base, int ld, int x0, int Xtot, int Ktot) {
+  if constexpr (KC) return make_srsrc(base + (int64_t)x0 * ld, (int64_t)(Xtot - x0) * ld * 2);
+  else return make_srsrc(base + x0, ((int64_t)Ktot * ld - x0) * 2);
+}
+
+template <bool KC, int XR>
+__device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld, int k0, int Ktot) {
+  const int l = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int PPW = XR / 64;
+  if constexpr (KC) {
+    unsigned offs[PPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (l & 15);
-    if (m >= g.M) continue;
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = w + 8 * i;                       // piece = 8 rows x 128 B; a wave's pieces are 8 KiB apart
+      const int row = pc * 8 + (l >> 3);
+      const int kc = (l & 7) ^ kc_swz(row);           // source chunk whose home is slot (l&7) of this row
+      unsigned off = (unsigned)(row * ld + k0 + kc * 8) * 2u;
+      if ((k0 + kc * 8) >= Ktot) off = 0xFFFFFFFFu;
+      offs[i] = off;
+    }
+    lds_dma16xN<PPW>(rs, offs, tile + w * 1024);
+  } else {
+    constexpr int SPR = XR / 8;                       // 16-B slots per k-row (32 or 16)
+    constexpr int RPP = 64 / SPR;                     // k-rows per piece (2 or 4)
+    unsigned offs[PPW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * (l >> 4);
-      if (n >= g.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const bool full = (n + 3) < g.N;
-      bf16* cp = C + (int64_t)m * g.ldc + n;
-      if (epi & MM_EPI_BIAS) {
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = w + 8 * i;
+      const int k = pc * RPP + l / SPR;
+      const int sl = l % SPR;
+      const int c32 = ((sl >> 1) - ks_swz(k)) & (XR / 16 - 1);   // rotation (not XOR): source stays two ascending runs per row
+      offs[i] = ((unsigned)(k0 + k) * (unsigned)ld + (unsigned)(c32 * 16 + (sl & 1) * 8)) * 2u;   // < 4 GiB by mm_gemm's check
+    }
+    lds_dma16xN<PPW>(rs, offs, tile + w * 1024);
+  }
+}
+
+template <bool KC, int XR>
+__device__ __forceinline__ bf16x8 frag_load2(const char* tile, int xb, int ks) {
+  const int l = threadIdx.x & 63;
+  if constexpr (KC) {
+    const int row = xb * 16 + (l & 15), kc = ks * 4 + (l >> 4);
+    return *(const bf16x8*)(tile + row * 128 + ((kc ^ kc_swz(row)) * 16));
+  } else {
+    constexpr int ROWB = XR * 2;
+    const int g = l >> 4, i = l & 15, q = i >> 2, p = i & 3;
+    const int k = ks * 32 + 8 * g + q;
+    const int sw = ((xb + ks_swz(k)) & (XR / 16 - 1)) * 32 + p * 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + k * ROWB + sw));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + (k + 4) * ROWB + sw));
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][A 32 KiB | B 16 KiB]
+  int pm, pn;
+  block_to_tile(blockIdx.x, g.nbm, g.nbn, pm, pn);
+  const int m0 = pm * G_BM, n0 = pn * G_BN;
+  const bf16* A = (const bf16*)g.A;
+  const bf16* B = (const bf16*)g.B;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm = w >> 1, wn = w & 1;
+
+  f32x4 acc[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (full || n + r < g.N) v[r] += (float)bias[n + r];
-      }
-      if (epi & MM_EPI_GELU_ERF) {
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_gelu_erf(v[r]);
-      } else if (epi & MM_EPI_QUICK_GELU) {
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + G_BK - 1) / G_BK;
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);     // LDS byte address of the ring
+  const SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
+  const SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
+  auto issue = [&](int t) {
+    const unsigned st = lds0 + (unsigned)((t % G_STAGES) * G_STAGE_BYTES);
+    dma_tile<A_KC, G_BM>(st, ra, g.lda, t * G_BK, g.K);
+    dma_tile<B_KC, G_BN>(st + G_A_BYTES, rb, g.ldb, t * G_BK, g.K);
+  };
+  issue(0);
+  if (nk > 1) issue(1);
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nk) issue(t + 2);
+    const char* cur = smem + (t % G_STAGES) * G_STAGE_BYTES;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_quick_gelu(v[r]);
-      }
-      if (epi & MM_EPI_RESIDUAL) {
-        const bf16* rp = R + (int64_t)m * g.ldr + n;
-        if (full) {
-          bf16x4 rv = *(const bf16x4*)rp;
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-        } else {
-          for (int r = 0; r < 4; ++r)
-            if (n + r < g.N) v[r] += (float)rp[r];
-        }
-      }
-      if (epi & MM_EPI_ACCUMULATE) {
-        if (full) {
-          bf16x4 cv = *(const bf16x4*)cp;
+      for (int i = 0; i < 4; ++i) fa[i] = frag_load2<A_KC, G_BM>(cur, wm * 4 + i, ks);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)cv[r];
-        } else {
-          for (int r = 0; r < 4; ++r)
-            if (n + r < g.N) v[r] += (float)cp[r];
-        }
-      }
-      if (full) {
-        bf16x4 o;
+      for (int j = 0; j < 4; ++j) fb[j] = frag_load2<B_KC, G_BN>(cur + G_A_BYTES, wn * 4 + j, ks);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-        *(bf16x4*)cp = o;
-      } else {
-        for (int r = 0; r < 4; ++r)
-          if (n + r < g.N) cp[r] = (bf16)v[r];
-      }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
   }
+  gemm_epilogue(g, acc, m0 + wm * 64, n0 + wn * 64);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -358,16 +542,46 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
   if (dtype == MM_BF16) {
     if ((lda & 7) || (ldb & 7) || (ldc & 3) || ((epilogue & MM_EPI_RESIDUAL) && (ldr & 3))) return MM_ERR_ALIGN;
     if (!mm_aligned16(A) || !mm_aligned16(B) || (((uintptr_t)C) & 7)) return MM_ERR_ALIGN;
-    g.nbm = (M + BM - 1) / BM;
-    g.nbn = (N + BN - 1) / BN;
-    const int64_t nwg = (int64_t)g.nbm * g.nbn;
-    if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
-    const size_t lds = 4 * TILE_BYTES;
-    dim3 grid((unsigned)nwg), block(256);
-    switch (layout) {
-      case MM_GEMM_NT: hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, g); break;
-      case MM_GEMM_NN: hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, g); break;
-      default: hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, g); break;
+    // kernel choice: the LDS-DMA 256x128 kernel when its grid fills the chip, else the 128x128 register-staged one.
+    // MM_GEMM_KERNEL=v1|dma forces one (A/B benchmarking).
+    static const int forced = [] {
+      const char* e = getenv("MM_GEMM_KERNEL");
+      return !e ? 0 : (e[0] == 'v' ? 1 : 2);
+    }();
+    const int64_t tiles_dma = (int64_t)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+    // the DMA kernel addresses a K-strided operand with 32-bit byte offsets over the whole matrix
+    const bool fits32 = (layout == MM_GEMM_NT) || ((int64_t)K * ldb * 2 < 0xFFFFFFFFll && (layout != MM_GEMM_TN || (int64_t)K * lda * 2 < 0xFFFFFFFFll));
+    const bool use_dma = fits32 && (forced == 2 || (forced == 0 && tiles_dma >= 192));
+    if (use_dma) {
+      g.nbm = (M + G_BM - 1) / G_BM;
+      g.nbn = (N + G_BN - 1) / G_BN;
+      if (tiles_dma > 0x7FFFFFFF) return MM_ERR_ARG;
+      const size_t lds = (size_t)G_STAGES * G_STAGE_BYTES;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+      }
+      dim3 grid((unsigned)tiles_dma), block(512);
+      switch (layout) {
+        case MM_GEMM_NT: hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, true>), grid, block, lds, s, g); break;
+        case MM_GEMM_NN: hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, false>), grid, block, lds, s, g); break;
+        default: hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false>), grid, block, lds, s, g); break;
+      }
+    } else {
+      g.nbm = (M + BM - 1) / BM;
+      g.nbn = (N + BN - 1) / BN;
+      const int64_t nwg = (int64_t)g.nbm * g.nbn;
+      if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+      const size_t lds = 4 * TILE_BYTES;
+      dim3 grid((unsigned)nwg), block(256);
+      switch (layout) {
+        case MM_GEMM_NT: hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, lds, s, g); break;
+        case MM_GEMM_NN: hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, lds, s, g); break;
+        default: hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, lds, s, g); break;
+      }
     }
   } else if (dtype == MM_F32) {
     g.nbm = (M + 63) / 64;
