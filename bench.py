@@ -181,7 +181,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ       # torchrun with one rank still rehearses the RCCL path
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from multimeditron_amd.model.model import MultimodalConfig, MultiModalModelForCausalLM
@@ -204,7 +205,7 @@ def main():
     batch, _ = synthetic_batch(B, S, n_img, P, vocab, special, 1234 + rank, dev, vis["image_size"])
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -217,7 +218,7 @@ def main():
         loss = trainer.training_step(batch)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -253,7 +254,7 @@ def main():
                                    "sample": c["sample"], "measured_seconds": round(c["seconds"], 2),
                                    "cpu_tflops": round(c["flops"] / c["seconds"] / 1e12, 3)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

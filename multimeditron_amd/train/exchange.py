@@ -6,7 +6,12 @@ enough that the first bucket leaves while the decoder is still back-propagating)
 LAST expected gradient write of every parameter that overlaps it has been enqueued; `async_op=True` puts the collective
 on the process group's own stream, ordered after the work enqueued so far, so it overlaps the rest of backward.
 How many writes a parameter receives per step (tied embedding / lm_head = 2) is learned during the first step, which
-therefore exchanges after backward."""
+therefore exchanges after backward.
+
+Collectives must be issued in the SAME order on every rank, but readiness order is data dependent (a text-only
+micro-batch never touches the vision tower).  So the launch sequence is fixed once: the order in which buckets
+completed during rank 0's first step, broadcast to all ranks; afterwards a bucket leaves only when it is ready AND every
+bucket before it in that sequence has left; whatever is still pending is flushed in sequence order after backward."""
 from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -23,11 +28,12 @@ class _Bucket:
 
 class GradExchanger:
     def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], segments: Sequence[Tuple[int, int, int]],
-                 bucket_elems: int, dist=None, group=None):
+                 bucket_elems: int, dist=None, group=None, force: bool = False):
         """ranges: trainable [start,end) of flat_grad; segments: (param_key, start, end) for every trainable param."""
         self.grad = flat_grad
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group) if dist is not None else 1
+        self.force = force
         self.buckets: List[_Bucket] = []
         for s, e in ranges:
             a = s
@@ -45,23 +51,43 @@ class GradExchanger:
         self._count: Dict[int, int] = {}
         self.launched_early = 0
         self.active = False
+        self.order: List[int] = list(range(len(self.buckets)))     # agreed launch sequence (bucket indices)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
+        self._tick = 0
+        self._last_touch = [0] * len(self.buckets)
+        self._bucket_index = {id(b): i for i, b in enumerate(self.buckets)}
 
     def begin_step(self, exchange_this_step: bool):
         self._count = {}
-        self.active = exchange_this_step and self.world > 1
+        self.active = exchange_this_step and (self.world > 1 or self.force)
         self.launched_early = 0
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
         for bk in self.buckets:
             bk.pending, bk.work = len(bk.params), None
 
     def on_ready(self, key: int):
         c = self._count.get(key, 0) + 1
         self._count[key] = c
-        if not self.active or self.expected is None or c != self.expected.get(key, 1):
+        if self.expected is None:                    # learning step: remember when each bucket was last written
+            self._tick += 1
+            for bk in self.param_buckets.get(key, ()):
+                self._last_touch[self._bucket_index[id(bk)]] = self._tick
+            return
+        if not self.active or c != self.expected.get(key, 1):
             return
         for bk in self.param_buckets.get(key, ()):
             bk.pending -= 1
             if bk.pending == 0:
-                self._launch(bk)
+                self._ready[self._bucket_index[id(bk)]] = True
+        self._drain(early=True)
+
+    def _drain(self, early: bool):
+        while self._next < len(self.order) and self._ready[self.order[self._next]]:
+            self._launch(self.buckets[self.order[self._next]])
+            self._next += 1
+            if early:
                 self.launched_early += 1
 
     def _launch(self, bk: _Bucket):
@@ -71,11 +97,17 @@ class GradExchanger:
         """Launch whatever has not left yet, then make the current stream wait for every bucket."""
         if self.expected is None:
             self.expected = dict(self._count)
+            # launch sequence = completion order of this first step on rank 0 (never-written buckets last)
+            order = sorted(range(len(self.buckets)), key=lambda i: (self._last_touch[i] == 0, self._last_touch[i], i))
+            if self.dist is not None and (self.world > 1 or self.force):
+                box = [order]
+                self.dist.broadcast_object_list(box, src=0, group=self.group)
+                order = list(box[0])
+            self.order = order
         if not self.active:
             return
-        for bk in self.buckets:
-            if bk.work is None:
-                self._launch(bk)
+        self._ready = [True] * len(self.buckets)
+        self._drain(early=False)
         for bk in self.buckets:
             bk.work.wait()
             bk.work = None

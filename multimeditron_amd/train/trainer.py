@@ -93,8 +93,10 @@ class MultimodalTrainer:
             off += e - s
         segs = [(id(seg.param), seg.start, seg.end) for seg in flat.segments if seg.param.requires_grad]
         self._trainable = [seg for seg in flat.segments if seg.param.requires_grad]
+        import os
+        force = bool(os.environ.get("MM_FORCE_EXCHANGE")) and self.dist is not None    # rehearse RCCL calls with 1 rank
         self.exchanger = GradExchanger(flat.grad, [(s, e) for s, e, _ in self.ranges], segs, self.bucket_elems,
-                                       dist=self.dist if self.world > 1 else None, group=self.pg)
+                                       dist=self.dist if (self.world > 1 or force) else None, group=self.pg, force=force)
 
     # ------------------------------------------------------------------ reference surface
     def compute_loss(self, model, inputs, return_outputs=False, **kwargs):

@@ -43,12 +43,19 @@ def _worker(rank, world, port, q):
             expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)) + step * world
             assert torch.equal(grad, expect), (rank, step)
             results.append(early_before_finish)
-        # step 0 learns the write counts -> nothing early; later steps launch from inside "backward"
+        # step 0 learns the write counts and the launch sequence -> nothing early; later steps launch from inside "backward"
         assert results[0] == [0, 0, 0, 0]
-        # bucket [600,900) and [900,1000) need key 3 twice; [300,600) needs key 2 and key 3(!) since 3 starts at 600 -> no
-        # after: 3 (1st) -> 0 ; 2 -> 0 (bucket [0,300) also needs key 1, bucket [300,600) needs only key 2 -> 1) ...
-        assert results[1][-1] == 4 and results[1][0] == 0 and results[1][2] >= results[1][1]
+        # learned completion order: [300,600) (key 2), then [600,900),[900,1000) (2nd write of key 3), then [0,300) (key 1)
+        assert ex.order == [1, 2, 3, 0], ex.order
+        assert results[1] == [0, 1, 3, 4], results[1]
         assert results[1] == results[2]
+        # a rank whose data skips a parameter (never ready) must still issue every collective, in the agreed order
+        grad.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+        ex.begin_step(True)
+        for k in ([3, 3, 1] if rank == 0 else order):      # rank 0 never writes key 2 this step
+            ex.on_ready(k)
+        ex.finish_step()
+        assert torch.equal(grad, torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))), rank
         # accumulation micro-step: no exchange
         grad.fill_(rank + 1.0)
         ex.begin_step(False)
