@@ -19,6 +19,11 @@
 
 #include "mm_common.h"
 
+// default DMA variant when both fit: 1 = 256x128 (3-stage ring), 2 = 256x256 (2 stages)
+#ifndef MM_DEFAULT_DMA_VARIANT
+#define MM_DEFAULT_DMA_VARIANT(tiles256) ((tiles256) >= 192 ? 2 : 1)
+#endif
+
 namespace {
 
 struct GemmArgs {
@@ -137,18 +142,19 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
 }
 
 // epilogue shared by the bf16 kernels: acc[i][j][r] = C[mw + i*16 + (l&15)][nw + j*16 + 4*(l>>4) + r]
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw) {
+template <int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
   const int l = threadIdx.x & 63;
   bf16* C = (bf16*)g.C;
   const bf16* bias = (const bf16*)g.bias;
   const bf16* R = (const bf16*)g.residual;
   const int epi = g.epi;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MREP; ++i) {
     const int m = mw + i * 16 + (l & 15);
     if (m >= g.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NREP; ++j) {
       const int n = nw + j * 16 + 4 * (l >> 4);
       if (n >= g.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue(g, acc, m0 + wm * 64, n0 + wn * 64);
+  gemm_epilogue<4, 4>(g, acc, m0 + wm * 64, n0 + wn * 64);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -264,8 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
 // LDS images are identical to v1 (swizzle applied on the per-lane SOURCE address, destination linear in lane
 // order as LDS-DMA requires), so fragment reads stay bank-conflict free.
 // ------------------------------------------------------------------------------------------------------
-constexpr int G_BM = 256, G_BN = 128, G_BK = 64, G_STAGES = 3;
-constexpr int G_A_BYTES = G_BM * G_BK * 2, G_B_BYTES = G_BN * G_BK * 2, G_STAGE_BYTES = G_A_BYTES + G_B_BYTES;
+constexpr int G_BK = 64;
 
 // LDS-DMA issued from inline asm so that hipcc's waitcnt pass does not know about it: with the builtin form the
 // compiler drains vmcnt(0) in front of every ds_read_b64_tr_b16 (it cannot disprove aliasing), which serialises the
@@ -382,55 +387,62 @@ __device__ __forceinline__ bf16x8 frag_load2(const char* tile, int xb, int ks) {
   }
 }
 
-template <bool A_KC, bool B_KC>
+// BMxBN block tile, 8 waves as WGM x WGN, STAGES-deep LDS ring (3: counted vmcnt keeps one tile in flight across the
+// barrier; 2: the next tile's DMA is issued right after the barrier and has one whole compute phase to land).
+template <bool A_KC, bool B_KC, int BM_, int BN_, int WGM, int STAGES>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][A 32 KiB | B 16 KiB]
+  constexpr int WGN = 8 / WGM;
+  constexpr int MREP = BM_ / WGM / 16, NREP = BN_ / WGN / 16;
+  constexpr int A_BYTES = BM_ * G_BK * 2, B_BYTES = BN_ * G_BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int DMA_PER_TILE = BM_ / 64 + BN_ / 64;
+  static_assert(STAGES == 2 || (STAGES == 3 && DMA_PER_TILE == 6), "vmcnt literal below");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   int pm, pn;
   block_to_tile(blockIdx.x, g.nbm, g.nbn, pm, pn);
-  const int m0 = pm * G_BM, n0 = pn * G_BN;
+  const int m0 = pm * BM_, n0 = pn * BN_;
   const bf16* A = (const bf16*)g.A;
   const bf16* B = (const bf16*)g.B;
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wm = w >> 1, wn = w & 1;
+  const int w = threadIdx.x >> 6;
+  const int wm = w / WGN, wn = w % WGN;
 
-  f32x4 acc[4][4];
+  f32x4 acc[MREP][NREP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MREP; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (g.K + G_BK - 1) / G_BK;
   const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);     // LDS byte address of the ring
   const SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
   const SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
   auto issue = [&](int t) {
-    const unsigned st = lds0 + (unsigned)((t % G_STAGES) * G_STAGE_BYTES);
-    dma_tile<A_KC, G_BM>(st, ra, g.lda, t * G_BK, g.K);
-    dma_tile<B_KC, G_BN>(st + G_A_BYTES, rb, g.ldb, t * G_BK, g.K);
+    const unsigned st = lds0 + (unsigned)((t % STAGES) * STAGE_BYTES);
+    dma_tile<A_KC, BM_>(st, ra, g.lda, t * G_BK, g.K);
+    dma_tile<B_KC, BN_>(st + A_BYTES, rb, g.ldb, t * G_BK, g.K);
   };
   issue(0);
-  if (nk > 1) issue(1);
+  if (STAGES == 3 && nk > 1) issue(1);
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (STAGES == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nk) issue(t + 2);
-    const char* cur = smem + (t % G_STAGES) * G_STAGE_BYTES;
+    if (t + STAGES - 1 < nk) issue(t + STAGES - 1);
+    const char* cur = smem + (t % STAGES) * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[MREP], fb[NREP];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag_load2<A_KC, G_BM>(cur, wm * 4 + i, ks);
+      for (int j = 0; j < NREP; ++j) fb[j] = frag_load2<B_KC, BN_>(cur + A_BYTES, wn * NREP + j, ks);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = frag_load2<B_KC, G_BN>(cur + G_A_BYTES, wn * 4 + j, ks);
+      for (int i = 0; i < MREP; ++i) fa[i] = frag_load2<A_KC, BM_>(cur, wm * MREP + i, ks);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MREP; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NREP; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     }
   }
-  gemm_epilogue(g, acc, m0 + wm * 64, n0 + wn * 64);
+  gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -545,31 +557,45 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
     // kernel choice: the LDS-DMA 256x128 kernel when its grid fills the chip, else the 128x128 register-staged one.
     // MM_GEMM_KERNEL=v1|dma forces one (A/B benchmarking).
     static const int forced = [] {
-      const char* e = getenv("MM_GEMM_KERNEL");
-      return !e ? 0 : (e[0] == 'v' ? 1 : 2);
+      const char* e = getenv("MM_GEMM_KERNEL");      // v1 | dma (256x128, 3 stages) | big (256x256, 2 stages)
+      return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'b' ? 3 : 2));
     }();
-    const int64_t tiles_dma = (int64_t)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-    // the DMA kernel addresses a K-strided operand with 32-bit byte offsets over the whole matrix
+    // the DMA kernels address a K-strided operand with 32-bit byte offsets over the whole matrix
     const bool fits32 = (layout == MM_GEMM_NT) || ((int64_t)K * ldb * 2 < 0xFFFFFFFFll && (layout != MM_GEMM_TN || (int64_t)K * lda * 2 < 0xFFFFFFFFll));
-    const bool use_dma = fits32 && (forced == 2 || (forced == 0 && tiles_dma >= 192));
-    if (use_dma) {
-      g.nbm = (M + G_BM - 1) / G_BM;
-      g.nbn = (N + G_BN - 1) / G_BN;
-      if (tiles_dma > 0x7FFFFFFF) return MM_ERR_ARG;
-      const size_t lds = (size_t)G_STAGES * G_STAGE_BYTES;
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-      }
-      dim3 grid((unsigned)tiles_dma), block(512);
+    const int64_t tiles_128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
+    const int64_t tiles_256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    int variant = 0;   // 0 = v1, 1 = 256x128x3, 2 = 256x256x2
+    if (fits32) {
+      if (forced == 2) variant = 1;
+      else if (forced == 3) variant = 2;
+      else if (forced == 0 && tiles_128 >= 192) variant = MM_DEFAULT_DMA_VARIANT(tiles_256);
+    }
+    if (variant) {
+      const int bn = variant == 1 ? 128 : 256;
+      g.nbm = (M + 255) / 256;
+      g.nbn = (N + bn - 1) / bn;
+      const int64_t nwg = (int64_t)g.nbm * g.nbn;
+      if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+      const size_t lds = variant == 1 ? 3 * (256 + 128) * G_BK * 2 : 2 * (256 + 256) * G_BK * 2;
+      dim3 grid((unsigned)nwg), block(512);
+#define MM_LAUNCH_DMA(AKC, BKC)                                                                                          \
+  do {                                                                                                                   \
+    if (variant == 1) {                                                                                                  \
+      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 128, 4, 3>;                                                          \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+      hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
+    } else {                                                                                                             \
+      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 256, 2, 2>;                                                          \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+      hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
+    }                                                                                                                    \
+  } while (0)
       switch (layout) {
-        case MM_GEMM_NT: hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, true>), grid, block, lds, s, g); break;
-        case MM_GEMM_NN: hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, false>), grid, block, lds, s, g); break;
-        default: hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false>), grid, block, lds, s, g); break;
+        case MM_GEMM_NT: MM_LAUNCH_DMA(true, true); break;
+        case MM_GEMM_NN: MM_LAUNCH_DMA(true, false); break;
+        default: MM_LAUNCH_DMA(false, false); break;
       }
+#undef MM_LAUNCH_DMA
     } else {
       g.nbm = (M + BM - 1) / BM;
       g.nbn = (N + BN - 1) / BN;
