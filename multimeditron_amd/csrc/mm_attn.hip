@@ -218,32 +218,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       for (int ds = 0; ds < NDS; ++ds)
         s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc_frag<BKV>(Kt, kb, ds), qf[ds], s_acc[kb], 0, 0, 0);
     }
+    // online softmax in base 2: p = exp2(s*sc - m); the scale is folded into one FMA per element and the row max is
+    // taken on the raw scores (sc > 0), so the unmasked path costs max + fma + v_exp + add (+ half a cvt) per element
     float mx = -INFINITY;
+    if (need_mask) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float tv = s_acc[kb][r] * sc;
-        if (need_mask) {
+        for (int r = 0; r < 16; ++r) {
           const int kl = kb * 32 + acc_row(r, h);
           bool ok = (kbits >> kl) & 1ull;
           if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
-          tv = ok ? tv : -INFINITY;
+          const float tv = ok ? s_acc[kb][r] : -INFINITY;
+          s_acc[kb][r] = tv;
+          mx = fmaxf(mx, tv);
         }
-        s_acc[kb][r] = tv;
-        mx = fmaxf(mx, tv);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s_acc[kb][r], s_acc[kb][r + 1]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
     const float m_new = fmaxf(m_run, mx);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_safe);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
     float rs = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s_acc[kb][r] - m_safe);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, -m_safe));
         rs += p;
         pf[kb][r >> 3][r & 7] = (bf16)p;
       }
@@ -494,10 +500,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
       const int ql = acc_row(r, h);
       bool ok = kvalid;
       if (a.causal) ok = ok && ki <= (qb + ql + shift);
+#ifdef MM_ATTN_DIAG_NOSOFTMAX
+      pf[r >> 3][r & 7] = (bf16)s_acc[r];
+      dsf[r >> 3][r & 7] = (bf16)dp_acc[r];
+#else
       const float p = ok ? exp2f(s_acc[r] * sc - rowc[ql]) : 0.f;
       const float dsv = p * (dp_acc[r] - rowc[32 + ql]) * a.scale;
       pf[r >> 3][r & 7] = (bf16)p;
       dsf[r >> 3][r & 7] = (bf16)dsv;
+#endif
     }
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
