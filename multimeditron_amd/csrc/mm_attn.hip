@@ -14,6 +14,8 @@
 // row-major tiles with a 32-byte XOR swizzle chosen so the transposed reads are conflict free.
 //
 // fp32 variants (parity path only) are plain wave-per-query-row kernels.
+#include <stdlib.h>
+
 #include "mm_common.h"
 
 namespace {
@@ -637,8 +639,431 @@ __global__ __launch_bounds__(64) void attn_bwd_f32_kernel(AttnArgs a, int D) {
   }
 }
 
+// ============================================================================================================
+// D = 128 fast path.  8 waves per workgroup (256 query rows / 256 keys), tiles streamed by LDS-DMA into a 2-deep ring
+// with ONE barrier per tile, 2 waves per SIMD so one wave's softmax VALU overlaps the other's MFMAs.
+// Every tile uses ONE LDS image that serves both row fragments (ds_read_b128) and transposed fragments
+// (ds_read_b64_tr_b16): plain 256-byte rows, 16-byte chunk index XOR ((row&3)<<2 | (row>>2)&3); the DMA destination is
+// linear in lane order, so the XOR is applied to the per-lane SOURCE chunk.
+// ============================================================================================================
+__device__ __forceinline__ int imgb_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int imgb_off(int row, int ch) { return 256 * row + 16 * (ch ^ imgb_swz(row)); }
+
+// DMA ROWS rows x 256 B (row stride in elements) starting at matrix row `row0`; 8 waves, ROWS/32 pieces (4 rows) each
+template <int ROWS, int NW = 8>
+__device__ __forceinline__ void imgb_dma(unsigned tile_lds, const SRsrc& rs, int64_t stride, int row0) {
+  const int l = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int PPW = ROWS / (4 * NW);
+  static_assert(PPW >= 1, "tile too small for this many waves");
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = w * PPW + i;
+    const int row = pc * 4 + (l >> 4);
+    const int ch = (l & 15) ^ imgb_swz(row);
+    const unsigned voff = (unsigned)(((int64_t)(row0 + row) * stride) * 2 + ch * 16);
+    lds_dma16(rs, voff, tile_lds + pc * 1024);
+  }
+}
+// row fragment (32 rows x 16 k): lane row = r0 + (l&31), k = kstep*16 + 8*(l>>5) .. +7
+__device__ __forceinline__ bf16x8 imgb_rowfrag(const char* tile, int r0, int kstep) {
+  const int l = threadIdx.x & 63;
+  return *(const bf16x8*)(tile + imgb_off(r0 + (l & 31), kstep * 2 + (l >> 5)));
+}
+// fragment of the transposed tile: A[row = column db*32 + (l&31)][k = tile row], k rows kbase..kbase+15 in the
+// accumulator-compatible order (element j of lane half h <-> tile row kbase + 8*(j>>2) + 4*h + (j&3))
+__device__ __forceinline__ bf16x8 imgb_tfrag(const char* tile, int db, int kbase) {
+  const int l = threadIdx.x & 63;
+  const int h = l >> 5, gi = (l >> 4) & 1, i = l & 15, q = i >> 2, p = i & 3;
+  const int row1 = kbase + 4 * h + q;
+  const int ch = db * 4 + gi * 2 + (p >> 1);
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + imgb_off(row1, ch) + 8 * (p & 1)));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, tile + imgb_off(row1 + 8, ch) + 8 * (p & 1)));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+__device__ __forceinline__ SRsrc rows_rsrc(const bf16* base, int nrows, int64_t stride) {
+  return make_srsrc(base, nrows > 0 ? ((int64_t)(nrows - 1) * stride + 128) * 2 : 0);
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
+  constexpr int BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
+  const int b = blockIdx.z, hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = blockIdx.x * 256 + w * 32;
+  const int qi = q0 + (l & 31);
+  const int shift = a.Skv - a.Sq;
+  const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
+  const SRsrc rk = rows_rsrc((const bf16*)a.k + b * a.k_sb + hkv * a.k_sh, a.Skv, a.k_ss);
+  const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+
+  bf16x8 qf[NDS];
+  {
+    const bf16* qrow = qi < a.Sq ? Q + (int64_t)qi * a.q_ss : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) qf[ds] = row_frag_global(qrow, ds);
+  }
+  f32x16 o_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc = a.scale * LOG2E;
+
+  int ntiles = (a.Skv + BKV - 1) / BKV;
+  if (a.causal) {
+    const int qmax = min(a.Sq - 1, (int)blockIdx.x * 256 + 255) + shift;
+    ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
+  }
+  auto issue = [&](int t) {
+    const unsigned st = lds0 + (unsigned)((t & 1) * 2 * TILE);
+    imgb_dma<BKV>(st, rk, a.k_ss, t * BKV);
+    imgb_dma<BKV>(st + TILE, rv, a.v_ss, t * BKV);
+  };
+  if (ntiles > 0) issue(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * BKV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < ntiles) issue(t + 1);
+    // wave-uniform skip: this wave's rows are all beyond Sq, or the whole tile lies above its causal diagonal
+    if (q0 >= a.Sq || (a.causal && kv0 > q0 + 31 + shift)) continue;
+    const char* Kt = smem + (t & 1) * 2 * TILE;
+    const char* Vt = Kt + TILE;
+    bool kvalid = (kv0 + l) < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + kv0 + l] != 0;
+    const unsigned long long kbits = __ballot(kvalid);
+    const bool need_mask = (kbits != ~0ull) || (a.causal && (kv0 + BKV - 1) > (q0 + shift));
+
+    f32x16 s_acc[2];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds)
+        s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_rowfrag(Kt, kb * 32, ds), qf[ds], s_acc[kb], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    float mx = -INFINITY;
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kl = kb * 32 + acc_row(r, h);
+          bool ok = (kbits >> kl) & 1ull;
+          if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
+          const float tv = ok ? s_acc[kb][r] : -INFINITY;
+          s_acc[kb][r] = tv;
+          mx = fmaxf(mx, tv);
+        }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s_acc[kb][r], s_acc[kb][r + 1]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    float rs = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, -m_safe));
+        rs += p;
+        pf[kb][r >> 3][r & 7] = (bf16)p;
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_tfrag(Vt, db, kb * 32 + s * 16), pf[kb][s], o_acc[db], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qi < a.Sq) {
+    bf16* orow = (bf16*)a.out + (((int64_t)b * a.Sq + qi) * a.Hq + hq) * 128;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(o_acc[db][rg * 4 + e] * inv);
+        *(bf16x4*)(orow + db * 32 + 8 * rg + 4 * h) = o;
+      }
+    if (h == 0) a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : INFINITY;
+  }
+}
+
+// dK/dV for D = 128: 4 waves x 32 keys, TWO workgroups per CU.  Register diet that makes 2 waves/SIMD fit: V fragments
+// come from an LDS image of the workgroup's 128 keys (not registers) and the Q / dO tiles arrive by LDS-DMA (no staging
+// registers) into a 2-deep ring, one barrier per query tile.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv128_kernel(AttnArgs a) {
+  constexpr int BQ = 32, NDS = 8, NDB = 4, QT = BQ * 256;            // 8 KiB per 32-row tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Vimg = smem;                                                   // 128 keys x 256 B
+  char* ring = smem + 128 * 256;                                       // [2 stages][Q 8 KiB | dO 8 KiB]
+  float* rowc = (float*)(smem + 128 * 256 + 4 * QT);                   // [2 stages][lse*log2e (32) | delta (32)]
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
+  const int b = blockIdx.z, hkv = blockIdx.y;
+  const int G = a.Hq / a.Hkv;
+  const int kblk = blockIdx.x * 128;
+  const int k0 = kblk + w * 32;
+  const int ki = k0 + (l & 31);
+  const int shift = a.Skv - a.Sq;
+  const bf16* K = (const bf16*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  {
+    const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+    imgb_dma<128, 4>(lds0, rv, a.v_ss, kblk);
+  }
+  bf16x8 kf[NDS];
+  {
+    const bf16* krow = ki < a.Skv ? K + (int64_t)ki * a.k_ss : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) kf[ds] = row_frag_global(krow, ds);
+  }
+  bool kvalid = ki < a.Skv;
+  if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + ki] != 0;
+  const float sc = a.scale * LOG2E;
+  f32x16 dk_acc[NDB], dv_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk_acc[i][r] = 0.f; dv_acc[i][r] = 0.f; }
+
+  int qt0 = 0;
+  if (a.causal) qt0 = max(0, kblk - shift) / BQ;
+  const int nqt = (a.Sq + BQ - 1) / BQ;
+  const int per_head = max(0, nqt - qt0);
+  const int niter = per_head * G;
+  const int64_t do_ss = (int64_t)a.Hq * 128;
+  float rc = 0.f;
+  auto issue = [&](int it) {
+    const int g = it / per_head, qb = (qt0 + it % per_head) * BQ;
+    const int hq = hkv * G + g;
+    const SRsrc rq = rows_rsrc((const bf16*)a.q + b * a.q_sb + hq * a.q_sh, a.Sq, a.q_ss);
+    const SRsrc rdo = rows_rsrc((const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128, a.Sq, do_ss);
+    const unsigned st = lds0 + 128 * 256 + (unsigned)((it & 1) * 2 * QT);
+    imgb_dma<BQ, 4>(st, rq, a.q_ss, qb);
+    imgb_dma<BQ, 4>(st + QT, rdo, do_ss, qb);
+    if (threadIdx.x < 64) {
+      const int qq = qb + (threadIdx.x & 31);
+      const int64_t ro = ((int64_t)b * a.Hq + hq) * a.Sq + qq;
+      if (threadIdx.x < 32) rc = qq < a.Sq ? a.lse[ro] * LOG2E : INFINITY;
+      else rc = qq < a.Sq ? a.delta[ro] : 0.f;
+    }
+  };
+  if (niter > 0) {
+    issue(0);
+    if (threadIdx.x < 64) rowc[threadIdx.x] = rc;
+  }
+  for (int it = 0; it < niter; ++it) {
+    const int qb = (qt0 + it % per_head) * BQ;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 1 < niter) issue(it + 1);
+    const char* Qt = ring + (it & 1) * 2 * QT;
+    const char* Ot = Qt + QT;
+    const float* rcs = rowc + (it & 1) * 64;
+    // wave-uniform skip: every key of this wave lies above the causal diagonal of every row of this query tile
+    if (!(a.causal && k0 > qb + BQ - 1 + shift)) {
+      f32x16 s_acc, dp_acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) {
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_rowfrag(Qt, 0, ds), kf[ds], s_acc, 0, 0, 0);
+        dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_rowfrag(Ot, 0, ds), imgb_rowfrag(Vimg, w * 32, ds), dp_acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = acc_row(r, h);
+        bool ok = kvalid;
+        if (a.causal) ok = ok && ki <= (qb + ql + shift);
+        const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], sc, -rcs[ql])) : 0.f;
+        const float dsv = p * (dp_acc[r] - rcs[32 + ql]) * a.scale;
+        pf[r >> 3][r & 7] = (bf16)p;
+        dsf[r >> 3][r & 7] = (bf16)dsv;
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_tfrag(Ot, db, s * 16), pf[s], dv_acc[db], 0, 0, 0);
+          dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_tfrag(Qt, db, s * 16), dsf[s], dk_acc[db], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // row constants of the NEXT tile: their ring slot was last read in iteration it-1, which every wave has left
+    if (it + 1 < niter && threadIdx.x < 64) rowc[((it + 1) & 1) * 64 + threadIdx.x] = rc;
+  }
+  if (ki < a.Skv) {
+    bf16* dkrow = (bf16*)a.dk + b * a.k_sb + hkv * a.k_sh + (int64_t)ki * a.k_ss;
+    bf16* dvrow = (bf16*)a.dv + b * a.v_sb + hkv * a.v_sh + (int64_t)ki * a.v_ss;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 ok_, ov_;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ok_[e] = (bf16)dk_acc[db][rg * 4 + e];
+          ov_[e] = (bf16)dv_acc[db][rg * 4 + e];
+        }
+        *(bf16x4*)(dkrow + db * 32 + 8 * rg + 4 * h) = ok_;
+        *(bf16x4*)(dvrow + db * 32 + 8 * rg + 4 * h) = ov_;
+      }
+  }
+}
+
+// dQ for D = 128: same shape as the forward fast path (8 waves, 256 query rows, K/V tiles by LDS-DMA, one barrier per
+// tile).  The single K image serves the row fragments of S^T = K.Q^T and the transposed fragments of dQ^T += K^T.dS^T.
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq128_kernel(AttnArgs a) {
+  constexpr int BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
+  const int b = blockIdx.z, hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = blockIdx.x * 256 + w * 32;
+  const int qi = q0 + (l & 31);
+  const int shift = a.Skv - a.Sq;
+  const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
+  const bf16* dO = (const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128;
+  const SRsrc rk = rows_rsrc((const bf16*)a.k + b * a.k_sb + hkv * a.k_sh, a.Skv, a.k_ss);
+  const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+
+  bf16x8 qf[NDS], dof[NDS];
+  {
+    const bf16* qrow = qi < a.Sq ? Q + (int64_t)qi * a.q_ss : nullptr;
+    const bf16* drow = qi < a.Sq ? dO + (int64_t)qi * a.Hq * 128 : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+      qf[ds] = row_frag_global(qrow, ds);
+      dof[ds] = row_frag_global(drow, ds);
+    }
+  }
+  const float sc = a.scale * LOG2E;
+  float lse2 = INFINITY, dlt = 0.f;
+  if (qi < a.Sq) {
+    lse2 = a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] * LOG2E;
+    dlt = a.delta[((int64_t)b * a.Hq + hq) * a.Sq + qi];
+  }
+  f32x16 dq_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq_acc[i][r] = 0.f;
+
+  int ntiles = (a.Skv + BKV - 1) / BKV;
+  if (a.causal) {
+    const int qmax = min(a.Sq - 1, (int)blockIdx.x * 256 + 255) + shift;
+    ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
+  }
+  auto issue = [&](int t) {
+    const unsigned st = lds0 + (unsigned)((t & 1) * 2 * TILE);
+    imgb_dma<BKV>(st, rk, a.k_ss, t * BKV);
+    imgb_dma<BKV>(st + TILE, rv, a.v_ss, t * BKV);
+  };
+  if (ntiles > 0) issue(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * BKV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < ntiles) issue(t + 1);
+    if (q0 >= a.Sq || (a.causal && kv0 > q0 + 31 + shift)) continue;
+    const char* Kt = smem + (t & 1) * 2 * TILE;
+    const char* Vt = Kt + TILE;
+    bool kvalid = (kv0 + l) < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + kv0 + l] != 0;
+    const unsigned long long kbits = __ballot(kvalid);
+    const bool need_mask = (kbits != ~0ull) || (a.causal && (kv0 + BKV - 1) > (q0 + shift));
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s_acc, dp_acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) {
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_rowfrag(Kt, kb * 32, ds), qf[ds], s_acc, 0, 0, 0);
+        dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_rowfrag(Vt, kb * 32, ds), dof[ds], dp_acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      bf16x8 dsf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], sc, -lse2));
+        if (need_mask) {
+          const int kl = kb * 32 + acc_row(r, h);
+          bool ok = (kbits >> kl) & 1ull;
+          if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
+          p = ok ? p : 0.f;
+        }
+        dsf[r >> 3][r & 7] = (bf16)(p * (dp_acc[r] - dlt) * a.scale);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          dq_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_tfrag(Kt, db, kb * 32 + s * 16), dsf[s], dq_acc[db], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  if (qi < a.Sq) {
+    bf16* drow = (bf16*)a.dq + b * a.q_sb + hq * a.q_sh + (int64_t)qi * a.q_ss;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)dq_acc[db][rg * 4 + e];
+        *(bf16x4*)(drow + db * 32 + 8 * rg + 4 * h) = o;
+      }
+  }
+}
+
+static bool attn_use_v1() {
+  static const bool v1 = [] { const char* e = getenv("MM_ATTN_KERNEL"); return e && e[0] == 'v'; }();
+  return v1;
+}
+
 template <int D>
 int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
+  if (D == 128 && !attn_use_v1()) {
+    const size_t lds = 2 * 2 * 64 * 256;
+    dim3 grid((a.Sq + 255) / 256, a.Hq, a.B), block(512);
+    (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd128_kernel, grid, block, lds, s, a);
+    return MM_OK;
+  }
   const size_t lds = 2 * 64 * D * 2;
   dim3 grid((a.Sq + 127) / 128, a.Hq, a.B), block(256);
   hipLaunchKernelGGL(attn_fwd_kernel<D>, grid, block, lds, s, a);
@@ -646,12 +1071,22 @@ int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
 }
 template <int D>
 int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
-  {
+  if (D == 128 && !attn_use_v1()) {
+    const size_t lds = 2 * 2 * 64 * 256;
+    dim3 grid((a.Sq + 255) / 256, a.Hq, a.B), block(512);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_dq128_kernel, grid, block, lds, s, a);
+  } else {
     const size_t lds = 3 * 64 * D * 2;
     dim3 grid((a.Sq + 127) / 128, a.Hq, a.B), block(256);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, block, lds, s, a);
   }
-  {
+  if (D == 128 && !attn_use_v1()) {
+    const size_t lds = 128 * 256 + 4 * 32 * 256 + 2 * 64 * sizeof(float);
+    dim3 grid((a.Skv + 127) / 128, a.Hkv, a.B), block(256);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_dkv128_kernel, grid, block, lds, s, a);
+  } else {
     const size_t lds = 4 * 32 * D * 2 + 64 * sizeof(float);
     dim3 grid((a.Skv + 127) / 128, a.Hkv, a.B), block(256);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<D>, grid, block, lds, s, a);

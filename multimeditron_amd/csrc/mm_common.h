@@ -72,5 +72,36 @@ __device__ __forceinline__ float block_max_256(float x, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds) issued from inline asm -----------------------------------------------
+// hipcc's waitcnt pass does not see these, so it neither drains them in front of ds_read_b64_tr_b16 nor counts them:
+// completion is tracked by hand (s_waitcnt vmcnt(N) + s_barrier before any wave reads the bytes).  The descriptor is
+// forced into SGPRs (wave-uniform by construction); out-of-range bytes are written as zeros by the hardware range check.
+struct SRsrc { unsigned w0, w1, w2, w3; };
+__device__ __forceinline__ SRsrc make_srsrc(const void* base, int64_t bytes) {
+  if (bytes < 0) bytes = 0;
+  const unsigned nb = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes;
+  const uint64_t a = (uint64_t)base;
+  SRsrc r;
+  r.w0 = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r.w1 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+  r.w2 = __builtin_amdgcn_readfirstlane(nb);
+  r.w3 = 0x00020000u;
+  return r;
+}
+// one 1-KiB piece: lane l's 16 bytes land at LDS byte address lds_addr + 16*l (lds_addr wave-uniform)
+__device__ __forceinline__ void lds_dma16(const SRsrc& r, unsigned voff, unsigned lds_addr) {
+  u32x4 d = {r.w0, r.w1, r.w2, r.w3};
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_addr), "s"(d)
+      : "memory");
+}
+
 static inline bool mm_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline int mm_elem_size(int dt) { return dt == MM_BF16 ? 2 : 4; }

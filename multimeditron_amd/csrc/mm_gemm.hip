@@ -272,22 +272,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------------
 constexpr int G_BK = 64;
 
-// LDS-DMA issued from inline asm so that hipcc's waitcnt pass does not know about it: with the builtin form the
-// compiler drains vmcnt(0) in front of every ds_read_b64_tr_b16 (it cannot disprove aliasing), which serialises the
-// ring.  Completion is tracked by hand (counted s_waitcnt vmcnt + s_barrier in the K loop).  The descriptor words are
-// forced into SGPRs with readfirstlane (they are wave-uniform by construction); M0 (LDS destination) is saved/restored.
-struct SRsrc { unsigned w0, w1, w2, w3; };
-__device__ __forceinline__ SRsrc make_srsrc(const void* base, int64_t bytes) {
-  if (bytes < 0) bytes = 0;
-  const unsigned nb = bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes;
-  const uint64_t a = (uint64_t)base;
-  SRsrc r;
-  r.w0 = __builtin_amdgcn_readfirstlane((unsigned)a);
-  r.w1 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
-  r.w2 = __builtin_amdgcn_readfirstlane(nb);
-  r.w3 = 0x00020000u;
-  return r;
-}
 // N LDS-DMA pieces of one operand tile in ONE asm statement: M0 saved/restored once, one hazard pad for the
 // freshly written descriptor SGPRs (the compiler pads nothing inside an asm string).
 template <int N>
