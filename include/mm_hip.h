@@ -84,14 +84,16 @@ int mm_drop_cls_bwd(int dtype, const void* ddst, int n, int P, int D, void* dsrc
 /* ---- norms ------------------------------------------------------------------------------------------
  * RMSNorm: HF:llama:53-70.  rstd[M] f32 is saved for backward.                                            */
 int mm_rmsnorm_fwd(int dtype, const void* x, const void* w, int M, int H, float eps, void* y, float* rstd, void* stream);
-/* dx = rstd*(g - xhat*mean(g*xhat)), g = dy*w;  dw_partial[nblk,H] f32 (nblk = mm_norm_bwd_blocks(M))        */
+/* dx = rstd*(g - xhat*mean(g*xhat)) (+ dres), g = dy*w;  dw_partial[nblk,H] f32 (nblk = mm_norm_bwd_blocks(M)).
+ * dres (optional, [M,H]) is the gradient arriving through the residual branch that shares x: fusing the add here
+ * replaces autograd's separate accumulation pass.                                                              */
 int mm_rmsnorm_bwd(int dtype, const void* dy, const void* x, const void* w, const float* rstd, int M, int H,
-                   void* dx, float* dw_partial, void* stream);
+                   void* dx, float* dw_partial, const void* dres, void* stream);
 /* LayerNorm: HF:clip:338-339,608 (nn.LayerNorm).  mean/rstd [M] f32 saved.                                 */
 int mm_layernorm_fwd(int dtype, const void* x, const void* w, const void* b, int M, int H, float eps, void* y,
                      float* mean, float* rstd, void* stream);
 int mm_layernorm_bwd(int dtype, const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
-                     int M, int H, void* dx, float* dw_partial, float* db_partial, void* stream);
+                     int M, int H, void* dx, float* dw_partial, float* db_partial, const void* dres, void* stream);
 int mm_norm_bwd_blocks(int M);
 /* out[H] (+)= sum_b partial[b,H]  (f32 partials -> param-dtype gradient)                                    */
 int mm_reduce_partials(int dtype, const float* partial, int nblk, int H, void* out, int accumulate, void* stream);

@@ -515,21 +515,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// column sums (bias gradients): block = 256 threads = 32 column groups (16 bytes each) x 8 row lanes; the grid also
+// splits the rows (gridDim.y) and finishes with float atomics into an f32 scratch only when needed -- here rows are
+// few enough (<= 8192) that one block per 32 column groups sweeping all rows with 8 row lanes is HBM-efficient.
 template <typename T>
-__global__ void colsum_kernel(const T* X, int M, int N, int ldx, T* out, int accumulate) {
-  // one block per 64 columns; 4 waves split the rows; lane = column
-  __shared__ float red[4][64];
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
-  float s = 0.f;
-  if (n < N)
-    for (int m = w; m < M; m += 4) s += to_f32(X[(int64_t)m * ldx + n]);
-  red[w][threadIdx.x & 63] = s;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, T* out, int accumulate) {
+  constexpr int VN = Vec16<T>::N;
+  __shared__ float red[8][32 * VN + 1];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n0 = (blockIdx.x * 32 + cg) * VN;
+  float acc[VN];
+#pragma unroll
+  for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+  if (n0 + VN <= N) {
+    for (int m = rl; m < M; m += 8) {
+      Vec16<T> v = *(const Vec16<T>*)(X + (int64_t)m * ldx + n0);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
+    }
+  } else if (n0 < N) {
+    for (int m = rl; m < M; m += 8)
+      for (int k = 0; k < VN && n0 + k < N; ++k) acc[k] += to_f32(X[(int64_t)m * ldx + n0 + k]);
+  }
+#pragma unroll
+  for (int k = 0; k < VN; ++k) red[rl][cg * VN + k] = acc[k];
   __syncthreads();
-  if (w == 0 && n < N) {
-    float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (accumulate) t += to_f32(out[n]);
-    out[n] = from_f32<T>(t);
+  for (int c = threadIdx.x; c < 32 * VN; c += 256) {
+    const int n = blockIdx.x * 32 * VN + c;
+    if (n < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red[r][c];
+      if (accumulate) t += to_f32(out[n]);
+      out[n] = from_f32<T>(t);
+    }
   }
 }
 
@@ -621,7 +640,9 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
 extern "C" int mm_colsum(int dtype, const void* X, int M, int N, int ldx, void* out, int accumulate, void* stream) {
   if (!X || !out || M < 0 || N <= 0) return MM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((N + 63) / 64), block(256);
+  const int vn = dtype == MM_BF16 ? 8 : 4;
+  if ((ldx % vn) || !mm_aligned16(X)) return MM_ERR_ALIGN;
+  dim3 grid((N + 32 * vn - 1) / (32 * vn)), block(256);
   if (dtype == MM_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, s, (const bf16*)X, M, N, ldx, (bf16*)out, accumulate);
   else

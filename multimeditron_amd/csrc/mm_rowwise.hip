@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int NORM_BWD_ROWS_PER_BLOCK = 64;
+constexpr int NORM_BWD_ROWS_PER_BLOCK = 16;   // 8192 rows -> 512 workgroups (2 per CU); dw partials stay small (nblk x H f32)
 
 // ---------------------------------------------------------------- RMSNorm
 // one block (256 threads) per row; row cached in registers (H <= 256*8*CH)
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* x, const T* w
 // block handles NORM_BWD_ROWS_PER_BLOCK rows; thread owns fixed columns -> dw partial in registers
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* x, const T* w, const float* rstd, int M, int H,
-                                                          T* dx, float* dwp) {
+                                                          T* dx, float* dwp, const T* dres) {
   __shared__ float red[8];
   constexpr int VN = Vec16<T>::N;
   float dw[CH][VN];
@@ -88,11 +88,12 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
     for (int c = 0; c < CH; ++c) {
       const int e = (c * 256 + threadIdx.x) * VN;
       if (e < H) {
-        Vec16<T> o;
+        Vec16<T> o, rv;
+        if (dres) rv = *(const Vec16<T>*)(dres + (int64_t)row * H + e);
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
           const float xh = xv[c].get(i) * rs;
-          o.set(i, rs * (gv[c].get(i) * wv[c].get(i) - xh * dot));
+          o.set(i, rs * (gv[c].get(i) * wv[c].get(i) - xh * dot) + (dres ? rv.get(i) : 0.f));
         }
         *(Vec16<T>*)(dx + (int64_t)row * H + e) = o;
       }
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const T*
 
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const T* w, const float* mean,
-                                                            const float* rstd, int M, int H, T* dx, float* dwp, float* dbp) {
+                                                            const float* rstd, int M, int H, T* dx, float* dwp, float* dbp, const T* dres) {
   __shared__ float red[8];
   constexpr int VN = Vec16<T>::N;
   float dw[CH][VN], db[CH][VN];
@@ -193,11 +194,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
     for (int c = 0; c < CH; ++c) {
       const int e = (c * 256 + threadIdx.x) * VN;
       if (e < H) {
-        Vec16<T> o;
+        Vec16<T> o, rv;
+        if (dres) rv = *(const Vec16<T>*)(dres + (int64_t)row * H + e);
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
           const float xh = (xv[c].get(i) - mu) * rs;
-          o.set(i, rs * (gv[c].get(i) * wv[c].get(i) - s1 - xh * s2));
+          o.set(i, rs * (gv[c].get(i) * wv[c].get(i) - s1 - xh * s2) + (dres ? rv.get(i) : 0.f));
         }
         *(Vec16<T>*)(dx + (int64_t)row * H + e) = o;
       }
@@ -215,14 +217,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
   }
 }
 
+// out[h] (+)= sum_b partial[b][h]: 64 columns x 4 row lanes per block, 4 independent loads in flight per thread
 template <typename T>
-__global__ void reduce_partials_kernel(const float* p, int nblk, int H, T* out, int accumulate) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= H) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += p[(int64_t)b * H + h];
-  if (accumulate) s += to_f32(out[h]);
-  out[h] = from_f32<T>(s);
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* p, int nblk, int H, T* out, int accumulate) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int h = blockIdx.x * 64 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (h < H) {
+    int b = rl;
+    for (; b + 12 < nblk; b += 16) {
+      s0 += p[(int64_t)b * H + h];
+      s1 += p[(int64_t)(b + 4) * H + h];
+      s2 += p[(int64_t)(b + 8) * H + h];
+      s3 += p[(int64_t)(b + 12) * H + h];
+    }
+    for (; b < nblk; b += 4) s0 += p[(int64_t)b * H + h];
+  }
+  red[rl][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rl == 0 && h < H) {
+    float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (accumulate) t += to_f32(out[h]);
+    out[h] = from_f32<T>(t);
+  }
 }
 
 // ---------------------------------------------------------------- RoPE
@@ -506,17 +524,17 @@ extern "C" int mm_rmsnorm_fwd(int dtype, const void* x, const void* w, int M, in
 }
 
 extern "C" int mm_rmsnorm_bwd(int dtype, const void* dy, const void* x, const void* w, const float* rstd, int M, int H, void* dx,
-                              float* dwp, void* stream) {
+                              float* dwp, const void* dres, void* stream) {
   if (!dy || !x || !w || !rstd || !dx || !dwp || M < 0 || H <= 0) return MM_ERR_ARG;
   if (M == 0) return MM_OK;
   hipStream_t s = (hipStream_t)stream;
   const int nb = mm_norm_bwd_blocks(M);
   if (dtype == MM_BF16) {
     if (H % 8) return MM_ERR_ALIGN;
-    DISPATCH_CH(bf16, norm_ch<bf16>(H), hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16, CH>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)w, rstd, M, H, (bf16*)dx, dwp));
+    DISPATCH_CH(bf16, norm_ch<bf16>(H), hipLaunchKernelGGL((rmsnorm_bwd_kernel<bf16, CH>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)w, rstd, M, H, (bf16*)dx, dwp, (const bf16*)dres));
   } else {
     if (H % 4) return MM_ERR_ALIGN;
-    DISPATCH_CH(float, norm_ch<float>(H), hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, CH>), dim3(nb), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)w, rstd, M, H, (float*)dx, dwp));
+    DISPATCH_CH(float, norm_ch<float>(H), hipLaunchKernelGGL((rmsnorm_bwd_kernel<float, CH>), dim3(nb), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)w, rstd, M, H, (float*)dx, dwp, (const float*)dres));
   }
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -539,17 +557,17 @@ extern "C" int mm_layernorm_fwd(int dtype, const void* x, const void* w, const v
 }
 
 extern "C" int mm_layernorm_bwd(int dtype, const void* dy, const void* x, const void* w, const float* mean, const float* rstd,
-                                int M, int H, void* dx, float* dwp, float* dbp, void* stream) {
+                                int M, int H, void* dx, float* dwp, float* dbp, const void* dres, void* stream) {
   if (!dy || !x || !w || !mean || !rstd || !dx || !dwp || !dbp || M < 0 || H <= 0) return MM_ERR_ARG;
   if (M == 0) return MM_OK;
   hipStream_t s = (hipStream_t)stream;
   const int nb = mm_norm_bwd_blocks(M);
   if (dtype == MM_BF16) {
     if (H % 8) return MM_ERR_ALIGN;
-    DISPATCH_CH(bf16, norm_ch<bf16>(H), hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, CH>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)w, mean, rstd, M, H, (bf16*)dx, dwp, dbp));
+    DISPATCH_CH(bf16, norm_ch<bf16>(H), hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, CH>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (const bf16*)w, mean, rstd, M, H, (bf16*)dx, dwp, dbp, (const bf16*)dres));
   } else {
     if (H % 4) return MM_ERR_ALIGN;
-    DISPATCH_CH(float, norm_ch<float>(H), hipLaunchKernelGGL((layernorm_bwd_kernel<float, CH>), dim3(nb), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, M, H, (float*)dx, dwp, dbp));
+    DISPATCH_CH(float, norm_ch<float>(H), hipLaunchKernelGGL((layernorm_bwd_kernel<float, CH>), dim3(nb), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, M, H, (float*)dx, dwp, dbp, (const float*)dres));
   }
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -558,7 +576,7 @@ extern "C" int mm_layernorm_bwd(int dtype, const void* dy, const void* x, const 
 extern "C" int mm_reduce_partials(int dtype, const float* partial, int nblk, int H, void* out, int accumulate, void* stream) {
   if (!partial || !out || nblk < 0 || H <= 0) return MM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((H + 255) / 256), block(256);
+  dim3 grid((H + 63) / 64), block(256);
   if (dtype == MM_BF16)
     hipLaunchKernelGGL(reduce_partials_kernel<bf16>, grid, block, 0, s, partial, nblk, H, (bf16*)out, accumulate);
   else

@@ -145,18 +145,23 @@ def linear(x, wg, bg=None, residual=None, act=0, ldc_pad=False, dummy=None):
 
 # --------------------------------------------------------------------------------------------------- norms
 class RMSNormFn(torch.autograd.Function):
+    """-> (y, x_res): x_res aliases x and is what the caller feeds to the residual add, so the gradient of the residual
+    branch arrives HERE and is added inside the norm-backward kernel (no separate autograd accumulation pass)."""
+
     @staticmethod
     def forward(ctx, x, dummy, w, eps):
         y, rstd = K.rmsnorm_fwd(x, w.data, eps)
         ctx.w = w
         ctx.save_for_backward(x, rstd)
-        return y
+        return y, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres):
         x, rstd = ctx.saved_tensors
         w = ctx.w
-        dx, dwp = K.rmsnorm_bwd(dy.contiguous(), x, w.data, rstd)
+        if dy is None:
+            return dres, None, None, None
+        dx, dwp = K.rmsnorm_bwd(dy.contiguous(), x, w.data, rstd, dres.contiguous() if dres is not None else None)
         if w.requires_grad:
             g, acc = grad_target(w)
             K.reduce_partials(dwp, g, acc)
@@ -174,13 +179,15 @@ class LayerNormFn(torch.autograd.Function):
         y, mean, rstd = K.layernorm_fwd(x, w.data, b.data, eps)
         ctx.w, ctx.b = w, b
         ctx.save_for_backward(x, mean, rstd)
-        return y
+        return y, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres):
         x, mean, rstd = ctx.saved_tensors
         w, b = ctx.w, ctx.b
-        dx, dwp, dbp = K.layernorm_bwd(dy.contiguous(), x, w.data, mean, rstd)
+        if dy is None:
+            return dres, None, None, None, None
+        dx, dwp, dbp = K.layernorm_bwd(dy.contiguous(), x, w.data, mean, rstd, dres.contiguous() if dres is not None else None)
         if w.requires_grad:
             g, acc = grad_target(w)
             K.reduce_partials(dwp, g, acc)

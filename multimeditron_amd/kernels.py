@@ -167,11 +167,11 @@ def norm_bwd_blocks(M):
     return _lib.lib().mm_norm_bwd_blocks(M)
 
 
-def rmsnorm_bwd(dy2d, x2d, w, rstd):
+def rmsnorm_bwd(dy2d, x2d, w, rstd, dres=None):
     M, H = x2d.shape
     dx = torch.empty_like(x2d)
     dwp = torch.empty((norm_bwd_blocks(M), H), dtype=torch.float32, device=x2d.device)
-    call("mm_rmsnorm_bwd", dt(x2d), _p(dy2d), _p(x2d), _p(w), _p(rstd), M, H, _p(dx), _p(dwp), _stream())
+    call("mm_rmsnorm_bwd", dt(x2d), _p(dy2d), _p(x2d), _p(w), _p(rstd), M, H, _p(dx), _p(dwp), _p(dres), _stream())
     return dx, dwp
 
 
@@ -184,13 +184,13 @@ def layernorm_fwd(x2d, w, b, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2d, x2d, w, mean, rstd):
+def layernorm_bwd(dy2d, x2d, w, mean, rstd, dres=None):
     M, H = x2d.shape
     dx = torch.empty_like(x2d)
     nb = norm_bwd_blocks(M)
     dwp = torch.empty((nb, H), dtype=torch.float32, device=x2d.device)
     dbp = torch.empty((nb, H), dtype=torch.float32, device=x2d.device)
-    call("mm_layernorm_bwd", dt(x2d), _p(dy2d), _p(x2d), _p(w), _p(mean), _p(rstd), M, H, _p(dx), _p(dwp), _p(dbp), _stream())
+    call("mm_layernorm_bwd", dt(x2d), _p(dy2d), _p(x2d), _p(w), _p(mean), _p(rstd), M, H, _p(dx), _p(dwp), _p(dbp), _p(dres), _stream())
     return dx, dwp, dbp
 
 

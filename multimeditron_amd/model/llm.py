@@ -113,14 +113,14 @@ class DecoderLayer(nn.Module):
 
     def forward(self, x, cos, sin, key_mask, B, S, cache=None):
         a = self.self_attn
-        h = self.input_layernorm(x)
+        h, x = self.input_layernorm(x)
         qkv = Fm.linear(h, a._wqkv, a._bqkv, dummy=grad_dummy(a.q_proj.weight))
         if cache is None:
             o = Fm.rope_attention(qkv, cos, sin, key_mask, B, S, a.Hq, a.Hkv, a.D, True, a.D ** -0.5)
         else:
             o = cache.attend(qkv, cos, sin, key_mask, B, S, a)
         x = a.o_proj(o, residual=x)
-        h = self.post_attention_layernorm(x)
+        h, x = self.post_attention_layernorm(x)
         gu = Fm.linear(h, self.mlp._wgu, None, dummy=grad_dummy(self.mlp.gate_proj.weight))
         act = Fm.swiglu(gu, self.mlp.I)
         return self.mlp.down_proj(act, residual=x)
@@ -253,7 +253,7 @@ class CausalLM(nn.Module):
             x = x.contiguous()
         for i, layer in enumerate(self.model.layers):
             x = layer(x, cos, sin, key_mask, B, S, cache=cache[i] if cache else None)
-        x = self.model.norm(x)
+        x, _ = self.model.norm(x)
         V = self.config.vocab_size
         if logits_to_keep:
             x = x.view(B, S, H)[:, -logits_to_keep:, :].reshape(-1, H)

@@ -103,11 +103,11 @@ class VisionLayer(nn.Module):
 
     def forward(self, x, n, T):
         a = self.self_attn
-        h = self.layer_norm1(x)
+        h, x = self.layer_norm1(x)
         qkv = Fm.linear(h, a._wqkv, a._bqkv, dummy=grad_dummy(a.q_proj.weight))
         o = Fm.rope_attention(qkv, None, None, None, n, T, a.heads, a.heads, a.hd, False, a.hd ** -0.5)
         x = a.out_proj(o, residual=x)
-        h = self.layer_norm2(x)
+        h, x = self.layer_norm2(x)
         h = self.mlp.fc1(h, act=self.mlp.act)
         return self.mlp.fc2(h, residual=x)
 
@@ -137,7 +137,7 @@ class VisionTransformer(nn.Module):
         x = self.embeddings(pixel_values)
         if stages is not None:
             stages["vit_embeddings"] = x.view(n, T, -1)
-        x = self.pre_layrnorm(x)
+        x, _ = self.pre_layrnorm(x)
         if stages is not None:
             stages["vit_pre_ln"] = x.view(n, T, -1)
         for i, layer in enumerate(self.encoder.layers):

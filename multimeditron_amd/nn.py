@@ -54,6 +54,8 @@ class Norm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(dim, dtype=dtype, device=device)) if bias else None
 
     def forward(self, x2d):
+        """-> (normed, x_res): use x_res (an alias of x2d) for the residual add so that its gradient is fused into the
+        norm-backward kernel."""
         d = grad_dummy(self.weight)
         if self.bias is None:
             return Fm.rmsnorm(x2d, self.weight, self.eps, dummy=d)

@@ -265,10 +265,11 @@ def test_norms(K, dtype, H):
     ref.backward(dy.float())
     y, rstd = K.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-5)
     assert rel(y.float(), ref.detach()) < tol
-    dx, dwp = K.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstd)
+    dres = rnd((M, H), dtype, 25)
+    dx, dwp = K.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstd, dres.cuda())
     dw = torch.empty(H, dtype=dtype, device="cuda")
     K.reduce_partials(dwp, dw, False)
-    assert rel(dx.float(), xf.grad) < tol * 2
+    assert rel(dx.float(), xf.grad + dres.float()) < tol * 2     # fused residual-gradient add
     assert rel(dw.float(), wf.grad) < tol * 2
     # LayerNorm
     xf, wf, bf = (t.float().clone().requires_grad_(True) for t in (x, w, b))
