@@ -16,6 +16,7 @@
 //
 // f32 path (parity only): 64x64x16 tiles on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include <stdlib.h>
+#include <string.h>
 
 #include "mm_common.h"
 
@@ -381,61 +382,88 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   constexpr int DMA_PER_TILE = BM_ / 64 + BN_ / 64;
   static_assert(STAGES == 2 || (STAGES == 3 && DMA_PER_TILE == 6), "vmcnt literal below");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int pm, pn;
-  block_to_tile(blockIdx.x, g.nbm, g.nbn, pm, pn);
-  const int m0 = pm * BM_, n0 = pn * BN_;
   const bf16* A = (const bf16*)g.A;
   const bf16* B = (const bf16*)g.B;
   const int w = threadIdx.x >> 6;
   const int wm = w / WGN, wn = w % WGN;
-
-  f32x4 acc[MREP][NREP];
-#pragma unroll
-  for (int i = 0; i < MREP; ++i)
-#pragma unroll
-    for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int nk = (g.K + G_BK - 1) / G_BK;
   const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);     // LDS byte address of the ring
-  const SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
-  const SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
-  auto issue = [&](int t) {
-    const unsigned st = lds0 + (unsigned)((t % STAGES) * STAGE_BYTES);
-    dma_tile<A_KC, BM_>(st, ra, g.lda, t * G_BK, g.K);
-    dma_tile<B_KC, BN_>(st + A_BYTES, rb, g.ldb, t * G_BK, g.K);
+  const int total = g.nbm * g.nbn;
+
+  // PERSISTENT workgroups: each walks tiles blockIdx.x, +gridDim.x, ... and treats their K-steps as ONE stream through
+  // the LDS ring, so the first DMA of the next tile is already in flight while this tile's epilogue stores run, and
+  // there is no per-tile dispatch / prologue bubble.  (tile id) & 7 == blockIdx.x & 7, so the XCD grouping of
+  // block_to_tile is preserved.
+  int tile = blockIdx.x;
+  if (tile >= total) return;
+  int pm, pn;
+  block_to_tile(tile, g.nbm, g.nbn, pm, pn);
+  int m0 = pm * BM_, n0 = pn * BN_;
+  SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
+  SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
+  auto issue = [&](const SRsrc& da, const SRsrc& db, int t, int stage) {
+    const unsigned st = lds0 + (unsigned)(stage * STAGE_BYTES);
+    dma_tile<A_KC, BM_>(st, da, g.lda, t * G_BK, g.K);
+    dma_tile<B_KC, BN_>(st + A_BYTES, db, g.ldb, t * G_BK, g.K);
   };
-  issue(0);
-  if (STAGES == 3 && nk > 1) issue(1);
-  for (int t = 0; t < nk; ++t) {
-    if (STAGES == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + STAGES - 1 < nk) issue(t + STAGES - 1);
-    const char* cur = smem + (t % STAGES) * STAGE_BYTES;
+  static_assert(STAGES == 2, "the persistent stream below is written for the 2-stage ring");
+  int sidx = 0;                                                       // global K-step counter (ring position)
+  issue(ra, rb, 0, 0);
+  while (true) {
+    f32x4 acc[MREP][NREP];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[MREP], fb[NREP];
+    for (int i = 0; i < MREP; ++i)
 #pragma unroll
-      for (int j = 0; j < NREP; ++j) fb[j] = frag_load2<B_KC, BN_>(cur + A_BYTES, wn * NREP + j, ks);
-#pragma unroll
-      for (int i = 0; i < MREP; ++i) fa[i] = frag_load2<A_KC, BM_>(cur, wm * MREP + i, ks);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MREP; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int next = tile + gridDim.x;
+    int nm0 = 0, nn0 = 0;
+    SRsrc nra = ra, nrb = rb;
+    if (next < total) {
+      int qm, qn;
+      block_to_tile(next, g.nbm, g.nbn, qm, qn);
+      nm0 = qm * BM_;
+      nn0 = qn * BN_;
+      nra = tile_rsrc<A_KC>(A, g.lda, nm0, g.M, g.K);
+      nrb = tile_rsrc<B_KC>(B, g.ldb, nn0, g.N, g.K);
     }
-  }
-#ifdef MM_GEMM_NOSTORE   // diagnostic build only: prices the epilogue
-  float keep = 0.f;
-  for (int i = 0; i < MREP; ++i)
-    for (int j = 0; j < NREP; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-  if (keep == 123.456f) ((float*)g.C)[0] = keep;
-#else
-  gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    for (int t = 0; t < nk; ++t, ++sidx) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const char* cur = smem + (sidx & 1) * STAGE_BYTES;
+#ifndef MM_GEMM_LATE_DMA
+      if (t + 1 < nk) issue(ra, rb, t + 1, (sidx + 1) & 1);
+      else if (next < total) issue(nra, nrb, 0, (sidx + 1) & 1);
 #endif
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#ifdef MM_GEMM_LATE_DMA
+        if (ks == 1) {   // experiment: start the MFMAs first, issue the next tile's DMA between the two k-steps
+          if (t + 1 < nk) issue(ra, rb, t + 1, (sidx + 1) & 1);
+          else if (next < total) issue(nra, nrb, 0, (sidx + 1) & 1);
+        }
+#endif
+        bf16x8 fa[MREP], fb[NREP];
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) fb[j] = frag_load2<B_KC, BN_>(cur + A_BYTES, wn * NREP + j, ks);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) fa[i] = frag_load2<A_KC, BM_>(cur, wm * MREP + i, ks);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+          for (int j = 0; j < NREP; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    if (next >= total) break;
+    tile = next;
+    m0 = nm0;
+    n0 = nn0;
+    ra = nra;
+    rb = nrb;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -554,6 +582,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
 
 }  // namespace
 
+static int g_opt_persist = 1;   // walk tiles with resident workgroups
+static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2 dma 256x128, 3 dma 256x256
+
+extern "C" int mm_set_option(const char* name, int value) {
+  if (!name) return MM_ERR_ARG;
+  if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 3) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
+  return MM_ERR_ARG;
+}
+
 extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                        int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream) {
   if (M < 0 || N < 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;
@@ -568,10 +606,11 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
     if (!mm_aligned16(A) || !mm_aligned16(B) || (((uintptr_t)C) & 7)) return MM_ERR_ALIGN;
     // kernel choice: the LDS-DMA 256x128 kernel when its grid fills the chip, else the 128x128 register-staged one.
     // MM_GEMM_KERNEL=v1|dma forces one (A/B benchmarking).
-    static const int forced = [] {
-      const char* e = getenv("MM_GEMM_KERNEL");      // v1 | dma (256x128, 3 stages) | big (256x256, 2 stages)
+    static const int forced_env = [] {
+      const char* e = getenv("MM_GEMM_KERNEL");      // v1 | dma (256x128) | big (256x256)
       return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'b' ? 3 : 2));
     }();
+    const int forced = g_opt_kernel ? g_opt_kernel : forced_env;
     // the DMA kernels address a K-strided operand with 32-bit byte offsets over the whole matrix
     const bool fits32 = (layout == MM_GEMM_NT) || ((int64_t)K * ldb * 2 < 0xFFFFFFFFll && (layout != MM_GEMM_TN || (int64_t)K * lda * 2 < 0xFFFFFFFFll));
     const int64_t tiles_128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
@@ -588,12 +627,15 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
       g.nbn = (N + bn - 1) / bn;
       const int64_t nwg = (int64_t)g.nbm * g.nbn;
       if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
-      const size_t lds = variant == 1 ? 3 * (256 + 128) * G_BK * 2 : 2 * (256 + 256) * G_BK * 2;
-      dim3 grid((unsigned)nwg), block(512);
+      const size_t lds = 2 * (256 + bn) * G_BK * 2;
+      static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
+      // persistent: one resident workgroup per CU (96 / 128 KiB of LDS each) walks the tiles; otherwise one tile each
+      const int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
+      dim3 grid((unsigned)nblk), block(512);
 #define MM_LAUNCH_DMA(AKC, BKC)                                                                                          \
   do {                                                                                                                   \
     if (variant == 1) {                                                                                                  \
-      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 128, 4, 3>;                                                          \
+      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 128, 4, 2>;                                                          \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
       hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
     } else {                                                                                                             \

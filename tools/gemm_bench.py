@@ -31,8 +31,34 @@ def operands(lay, M, N, Kd):
     return a[:, :M], r(Kd, N)
 
 
+def set_opt(name, v):
+    from multimeditron_amd._lib import lib
+    assert lib().mm_set_option(name.encode(), v) == 0
+
+
 def main():
     quick = "--quick" in sys.argv
+    if "--ab-persist" in sys.argv:        # same process, same device: interleaved A/B of the persistent tile loop
+        for lay, shapes in SHAPES.items():
+            for (M, N, Kd) in shapes:
+                a, b = operands(lay, M, N, Kd)
+                c = torch.empty(M, pad64(N), device="cuda", dtype=torch.bfloat16)[:, :N]
+                res = {0: [], 1: []}
+                for rnd in range(6):
+                    for mode in (0, 1):
+                        set_opt("gemm_persist", mode)
+                        K.gemm(LAY[lay], a, b, M, N, Kd, out=c)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(3):
+                            K.gemm(LAY[lay], a, b, M, N, Kd, out=c)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        res[mode].append(e0.elapsed_time(e1) / 3)
+                fl = 2.0 * M * N * Kd
+                med = {m: sorted(v)[len(v) // 2] for m, v in res.items()}
+                print(f"{lay} M={M:6d} N={N:6d} K={Kd:6d}  one-tile-per-wg {fl / med[0] / 1e9:7.1f} TF/s   persistent {fl / med[1] / 1e9:7.1f} TF/s", flush=True)
+        return
     tot_f = tot_t = 0.0
     for lay, shapes in SHAPES.items():
         for (M, N, Kd) in (shapes[:2] if quick else shapes):
