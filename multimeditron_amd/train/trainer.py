@@ -47,7 +47,8 @@ class MultimodalTrainer:
     def __init__(self, model, training_mode: TrainingMode = TrainingMode.ALIGNMENT, learning_rate: float = 1e-4,
                  weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 1.0,
                  gradient_accumulation_steps: int = 1, max_steps: int = 0, min_lr: Optional[float] = None, warmup_steps: int = 0,
-                 bucket_mb: int = 256, process_group=None, data_collator=None, train_dataset=None):
+                 bucket_mb: int = 256, process_group=None, data_collator=None, train_dataset=None,
+                 overlap_optimizer: bool = True):
         self.model = model
         self.training_mode = TrainingMode(training_mode)
         self.lr, self.wd, self.betas, self.eps = learning_rate, weight_decay, betas, eps
@@ -62,8 +63,10 @@ class MultimodalTrainer:
         self.pg = process_group
         self.world = self.dist.get_world_size(self.pg) if self.dist else 1
         self.bucket_elems = bucket_mb * 1024 * 1024 // 2
+        self.overlap_optimizer = overlap_optimizer
         self._set_mode()
         self._setup_state()
+        self._setup_optimizer_pipeline()
 
     # ------------------------------------------------------------------ setup
     def _set_mode(self):
@@ -119,6 +122,7 @@ class MultimodalTrainer:
         try:
             loss = self.compute_loss(self.model, inputs)
             # mean over micro-batches and ranks (HF Trainer with model_accepts_loss_kwargs=False, trainer.py:80)
+            self._wait_optimizer()      # the previous update still reads the flat gradient buffer on the side stream
             if loss.requires_grad:      # e.g. ALIGNMENT mode on a text-only micro-batch: nothing trainable is on the path
                 loss.backward(gradient=torch.full_like(loss, 1.0 / (self.accum * self.world)))
         finally:
@@ -138,16 +142,115 @@ class MultimodalTrainer:
             ex.finish_step()
         return loss.detach()
 
+    # ------------------------------------------------------------------ optimiser, overlapped with the next forward
+    def _setup_optimizer_pipeline(self):
+        """AdamW is HBM-bound (30 B/param), the forward pass is MFMA-bound: run the update of step n on a side HIP stream
+        while step n+1's forward runs, block by block in FORWARD order (vision tower, projector, embedding, decoder layers,
+        final norm, lm_head).  A forward pre-hook on each block makes the compute stream wait for that block's update
+        event, and the compute stream waits for the last event before the next backward writes gradients."""
+        import re
+        self._blocks = []          # [(module or None, [(start, end, decay, state_off)])] in forward order
+        if not self.overlap_optimizer:
+            return
+        state_off = {}
+        for (s0, e0, _), off in zip(self.ranges, self.state_off):
+            state_off[(s0, e0)] = off
+
+        def st_off(start):
+            for (s0, e0), off in state_off.items():
+                if s0 <= start < e0:
+                    return off + (start - s0)
+            raise KeyError(start)
+
+        def block_key(name):
+            m = re.match(r"(.*?layers\.\d+)\.", name)
+            return m.group(1) if m else name.rsplit(".", 1)[0]
+
+        groups: Dict[str, List] = {}
+        for seg in self._trainable:
+            groups.setdefault(block_key(seg.name), []).append(seg)
+
+        def order(key):    # forward order: modality towers (embeddings, pre-norm, layers, projector), then the LLM
+            llm = key.startswith("model.")
+            m = re.search(r"layers\.(\d+)$", key)
+            li = int(m.group(1)) if m else -1
+            if not llm:
+                rank = 3 if ".projector" in key else (2 if li >= 0 else (0 if "embeddings" in key else 1))
+            else:
+                rank = 10 if "embed_tokens" in key else (11 if li >= 0 else (12 if key.endswith(".norm") else 13))
+            return (rank, li, key)
+
+        for key in sorted(groups, key=order):
+            segs = sorted(groups[key], key=lambda sg: sg.start)
+            runs = []
+            for sg in segs:                                   # merge adjacent slices with equal decay flag
+                end = min((sg.end + 7) // 8 * 8, self.flat.numel)
+                if runs and runs[-1][1] == sg.start and runs[-1][2] == sg.decay:
+                    runs[-1][1] = end
+                else:
+                    runs.append([sg.start, end, sg.decay])
+            try:
+                mod = self.model.get_submodule(key)
+            except AttributeError:
+                mod = None
+            self._blocks.append((mod, [(a, b, d, st_off(a)) for a, b, d in runs]))
+        covered = sum(b - a for _, rs in self._blocks for a, b, _, _ in rs)
+        assert covered == sum(e - s0 for s0, e, _ in self.ranges), "optimizer pipeline must cover every trainable range"
+        self._opt_stream = torch.cuda.Stream()
+        self._pending: Dict[int, torch.cuda.Event] = {}
+        self._all_done: Optional[torch.cuda.Event] = None
+        self._hooks = []
+        for mod, _ in self._blocks:
+            if mod is not None:
+                self._hooks.append(mod.register_forward_pre_hook(self._wait_block))
+
+    def _wait_block(self, mod, _inputs):
+        ev = self._pending.pop(id(mod), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _wait_optimizer(self):
+        """Everything the side stream still owes (before gradients are overwritten or parameters read ad hoc)."""
+        if getattr(self, "_all_done", None) is not None:
+            torch.cuda.current_stream().wait_event(self._all_done)
+            self._all_done = None
+            self._pending.clear()
+
     def _optimizer_step(self):
         self.step_count += 1
         lr = cosine_with_min_lr(self.step_count - 1, self.max_steps, self.lr, self.min_lr, self.warmup)
         g = self.flat.grad
         total = K.gradnorm([g[s:e] for s, e, _ in self.ranges], self.max_grad_norm if self.max_grad_norm else 0.0)
         self.last_grad_norm = total
-        for (s, e, decay), off in zip(self.ranges, self.state_off):
+
+        def upd(s, e, decay, off):
             n = e - s
             K.adamw_step(self.flat.data[s:e], g[s:e], self.master[off:off + n], self.m[off:off + n], self.v[off:off + n], lr,
                          self.betas[0], self.betas[1], self.eps, self.wd if decay else 0.0, self.step_count, clip=total)
+
+        if not self._blocks:
+            for (s, e, decay), off in zip(self.ranges, self.state_off):
+                upd(s, e, decay, off)
+            return
+        main = torch.cuda.current_stream()
+        side = self._opt_stream
+        side.wait_stream(main)                               # gradients (and their all-reduce) are complete
+        with torch.cuda.stream(side):
+            for mod, runs in self._blocks:
+                for s, e, decay, off in runs:
+                    upd(s, e, decay, off)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                if mod is not None:
+                    self._pending[id(mod)] = ev
+            self._all_done = ev
+        # blocks without a hookable module: wait for them right away
+        if any(mod is None for mod, _ in self._blocks):
+            main.wait_event(self._all_done)
+
+    def synchronize(self):
+        """Make the compute stream wait for the in-flight optimiser update (call before reading parameters)."""
+        self._wait_optimizer()
 
     def train(self, batches: Optional[Iterable[Dict[str, Any]]] = None, max_steps: Optional[int] = None):
         """Minimal loop: iterate collated batches (or collate `train_dataset` with `data_collator` in fixed-size chunks)."""

@@ -46,6 +46,7 @@ def _rank(rank, world, port, tmp, q):
         for step in cases:
             tr.training_step(to_device(R.golden_batch(v, step[rank])))
             early.append(tr.exchanger.launched_early)
+        tr.synchronize()
         torch.cuda.synchronize()
         sd = {k: p.detach().float().cpu().numpy() for k, p in model.named_parameters()}   # by value through the queue
         q.put((rank, "ok", sd if rank == 0 else None, early, len(tr.exchanger.buckets)))
@@ -83,6 +84,7 @@ def test_dp2_equals_grad_accumulation(tmp_path):
     for a, b in [("right", "interleaved4"), ("left", "textonly"), ("interleaved4", "right")]:
         tr.training_step(to_device(R.golden_batch(v, a)))
         tr.training_step(to_device(R.golden_batch(v, b)))
+    tr.synchronize()
     torch.cuda.synchronize()
     for k, p in model.named_parameters():
         ref = p.detach().float().cpu()

@@ -22,6 +22,7 @@ def test_training_steps_match_oracle(golden_dir, tmp_path, name, mode):
                            max_grad_norm=1.0, gradient_accumulation_steps=1)
     cases = ["right", "textonly", "interleaved4"]     # the text-only step leaves the vision tower without gradients
     losses = [float(tr.training_step(to_device(R.golden_batch(v, c)))) for c in cases]
+    tr.synchronize()
     torch.cuda.synchronize()
 
     # oracle: same weights, torch autograd + AdamW on CPU
