@@ -275,9 +275,9 @@ constexpr int G_BK = 64;
 
 // N LDS-DMA pieces of one operand tile in ONE asm statement: M0 saved/restored once, one hazard pad for the
 // freshly written descriptor SGPRs (the compiler pads nothing inside an asm string).
-template <int N>
+template <int N, int STEP>
 __device__ __forceinline__ void lds_dma16xN(const SRsrc& r, const unsigned (&voff)[N], unsigned lds_addr0) {
-  static_assert(N == 2 || N == 4, "pieces per wave");
+  static_assert(N == 2 || N == 4, "pieces per call");
   u32x4 d = {r.w0, r.w1, r.w2, r.w3};
   unsigned keep;
   if constexpr (N == 4) {
@@ -286,15 +286,15 @@ __device__ __forceinline__ void lds_dma16xN(const SRsrc& r, const unsigned (&vof
         "s_mov_b32 m0, %5\n\t"
         "s_nop 4\n\t"
         "buffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_add_u32 m0, m0, %7\n\t"
         "buffer_load_dwordx4 %2, %6, 0 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_add_u32 m0, m0, %7\n\t"
         "buffer_load_dwordx4 %3, %6, 0 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_add_u32 m0, m0, %7\n\t"
         "buffer_load_dwordx4 %4, %6, 0 offen lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(lds_addr0), "s"(d)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(lds_addr0), "s"(d), "i"(STEP)
         : "memory", "scc");
   } else {
     asm volatile(
@@ -302,16 +302,15 @@ __device__ __forceinline__ void lds_dma16xN(const SRsrc& r, const unsigned (&vof
         "s_mov_b32 m0, %3\n\t"
         "s_nop 4\n\t"
         "buffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_add_u32 m0, m0, %5\n\t"
         "buffer_load_dwordx4 %2, %4, 0 offen lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff[0]), "v"(voff[1]), "s"(lds_addr0), "s"(d)
+        : "v"(voff[0]), "v"(voff[1]), "s"(lds_addr0), "s"(d), "i"(STEP)
         : "memory", "scc");
   }
 }
 
-// issue the LDS-DMA of one operand tile ([XR rows/cols] x 64 k) into `tile`; every wave moves XR/64 1-KiB pieces
 // descriptor of one operand anchored at the tile origin (k = 0); built once per workgroup
 template <bool KC>
 __device__ __forceinline__ SRsrc tile_rsrc(const bf16* base, int ld, int x0, int Xtot, int Ktot) {
@@ -319,36 +318,36 @@ __device__ __forceinline__ SRsrc tile_rsrc(const bf16* base, int ld, int x0, int
   else return make_srsrc(base + x0, ((int64_t)Ktot * ld - x0) * 2);
 }
 
-template <bool KC, int XR>
+// NW = number of waves that issue the tile's DMA (8 = all; 4 = waves 0-3 only, which staggers the two waves of a SIMD)
+template <bool KC, int XR, int NW>
 __device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld, int k0, int Ktot) {
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int PPW = XR / 64;
-  if constexpr (KC) {
-    unsigned offs[PPW];
+  constexpr int PPW = XR / (8 * NW);      // 1-KiB pieces per issuing wave
+  constexpr int CALLS = PPW > 4 ? PPW / 4 : 1, PER = PPW > 4 ? 4 : PPW;
+  if (w >= NW) return;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int pc = w + 8 * i;                       // piece = 8 rows x 128 B; a wave's pieces are 8 KiB apart
-      const int row = pc * 8 + (l >> 3);
-      const int kc = (l & 7) ^ kc_swz(row);           // source chunk whose home is slot (l&7) of this row
-      unsigned off = (unsigned)(row * ld + k0 + kc * 8) * 2u;
-      if ((k0 + kc * 8) >= Ktot) off = 0xFFFFFFFFu;
-      offs[i] = off;
-    }
-    lds_dma16xN<PPW>(rs, offs, tile + w * 1024);
-  } else {
-    constexpr int SPR = XR / 8;                       // 16-B slots per k-row (32 or 16)
-    constexpr int RPP = 64 / SPR;                     // k-rows per piece (2 or 4)
-    unsigned offs[PPW];
+  for (int c = 0; c < CALLS; ++c) {
+    unsigned offs[PER];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int pc = w + 8 * i;
-      const int k = pc * RPP + l / SPR;
-      const int sl = l % SPR;
-      const int c32 = ((sl >> 1) - ks_swz(k)) & (XR / 16 - 1);   // rotation (not XOR): source stays two ascending runs per row
-      offs[i] = ((unsigned)(k0 + k) * (unsigned)ld + (unsigned)(c32 * 16 + (sl & 1) * 8)) * 2u;   // < 4 GiB by mm_gemm's check
+    for (int i = 0; i < PER; ++i) {
+      const int pc = w + NW * (c * PER + i);
+      if constexpr (KC) {                 // piece = 8 rows x 128 B
+        const int row = pc * 8 + (l >> 3);
+        const int kc = (l & 7) ^ kc_swz(row);           // source chunk whose home is slot (l&7) of this row
+        unsigned off = (unsigned)(row * ld + k0 + kc * 8) * 2u;
+        if ((k0 + kc * 8) >= Ktot) off = 0xFFFFFFFFu;
+        offs[i] = off;
+      } else {
+        constexpr int SPR = XR / 8;       // 16-B slots per k-row (32 or 16)
+        constexpr int RPP = 64 / SPR;     // k-rows per piece (2 or 4)
+        const int k = pc * RPP + l / SPR;
+        const int sl = l % SPR;
+        const int c32 = ((sl >> 1) - ks_swz(k)) & (XR / 16 - 1);   // rotation: the source stays two ascending runs per row
+        offs[i] = ((unsigned)(k0 + k) * (unsigned)ld + (unsigned)(c32 * 16 + (sl & 1) * 8)) * 2u;   // < 4 GiB by mm_gemm's check
+      }
     }
-    lds_dma16xN<PPW>(rs, offs, tile + w * 1024);
+    lds_dma16xN<PER, NW * 1024>(rs, offs, tile + (w + NW * c * PER) * 1024);
   }
 }
 
@@ -374,13 +373,11 @@ __device__ __forceinline__ bf16x8 frag_load2(const char* tile, int xb, int ks) {
 
 // BMxBN block tile, 8 waves as WGM x WGN, STAGES-deep LDS ring (3: counted vmcnt keeps one tile in flight across the
 // barrier; 2: the next tile's DMA is issued right after the barrier and has one whole compute phase to land).
-template <bool A_KC, bool B_KC, int BM_, int BN_, int WGM, int STAGES>
+template <bool A_KC, bool B_KC, int BM_, int BN_, int WGM, int STAGES, int ISSUE_WAVES>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   constexpr int WGN = 8 / WGM;
   constexpr int MREP = BM_ / WGM / 16, NREP = BN_ / WGN / 16;
   constexpr int A_BYTES = BM_ * G_BK * 2, B_BYTES = BN_ * G_BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int DMA_PER_TILE = BM_ / 64 + BN_ / 64;
-  static_assert(STAGES == 2 || (STAGES == 3 && DMA_PER_TILE == 6), "vmcnt literal below");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bf16* A = (const bf16*)g.A;
   const bf16* B = (const bf16*)g.B;
@@ -403,8 +400,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
   auto issue = [&](const SRsrc& da, const SRsrc& db, int t, int stage) {
     const unsigned st = lds0 + (unsigned)(stage * STAGE_BYTES);
-    dma_tile<A_KC, BM_>(st, da, g.lda, t * G_BK, g.K);
-    dma_tile<B_KC, BN_>(st + A_BYTES, db, g.ldb, t * G_BK, g.K);
+    dma_tile<A_KC, BM_, ISSUE_WAVES>(st, da, g.lda, t * G_BK, g.K);
+    dma_tile<B_KC, BN_, ISSUE_WAVES>(st + A_BYTES, db, g.ldb, t * G_BK, g.K);
   };
   static_assert(STAGES == 2, "the persistent stream below is written for the 2-stage ring");
   int sidx = 0;                                                       // global K-step counter (ring position)
@@ -584,10 +581,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
 
 static int g_opt_persist = 1;   // walk tiles with resident workgroups
 static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2 dma 256x128, 3 dma 256x256
+static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
 
 extern "C" int mm_set_option(const char* name, int value) {
   if (!name) return MM_ERR_ARG;
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_issue_waves")) { if (value != 2 && value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 3) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -635,11 +634,19 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
 #define MM_LAUNCH_DMA(AKC, BKC)                                                                                          \
   do {                                                                                                                   \
     if (variant == 1) {                                                                                                  \
-      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 128, 4, 2>;                                                          \
+      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 128, 4, 2, 8>;                                                       \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+      hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
+    } else if (g_opt_issue_waves == 2) {                                                                                 \
+      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 256, 2, 2, 2>;                                                       \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+      hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
+    } else if (g_opt_issue_waves == 4) {                                                                                 \
+      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 256, 2, 2, 4>;                                                       \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
       hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
     } else {                                                                                                             \
-      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 256, 2, 2>;                                                          \
+      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 256, 2, 2, 8>;                                                       \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
       hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
     }                                                                                                                    \

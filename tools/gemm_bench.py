@@ -38,6 +38,34 @@ def set_opt(name, v):
 
 def main():
     quick = "--quick" in sys.argv
+    ab = [a for a in sys.argv if a.startswith("--ab=")]
+    if ab:                                # same process, same device: interleaved A/B of one option, e.g. --ab=gemm_issue_waves:8:4
+        name, v0, v1 = ab[0][5:].split(":")
+        v0, v1 = int(v0), int(v1)
+        tot = {v0: 0.0, v1: 0.0}
+        for lay, shapes in SHAPES.items():
+            for (M, N, Kd) in shapes:
+                a, b = operands(lay, M, N, Kd)
+                c = torch.empty(M, pad64(N), device="cuda", dtype=torch.bfloat16)[:, :N]
+                res = {v0: [], v1: []}
+                for rnd in range(6):
+                    for mode in (v0, v1):
+                        set_opt(name, mode)
+                        K.gemm(LAY[lay], a, b, M, N, Kd, out=c)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(3):
+                            K.gemm(LAY[lay], a, b, M, N, Kd, out=c)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        res[mode].append(e0.elapsed_time(e1) / 3)
+                fl = 2.0 * M * N * Kd
+                med = {m: sorted(v)[len(v) // 2] for m, v in res.items()}
+                for m in med:
+                    tot[m] += med[m]
+                print(f"{lay} M={M:6d} N={N:6d} K={Kd:6d}  {name}={v0}: {fl / med[v0] / 1e9:7.1f} TF/s   {name}={v1}: {fl / med[v1] / 1e9:7.1f} TF/s", flush=True)
+        print("TOTAL ms", tot)
+        return
     if "--ab-persist" in sys.argv:        # same process, same device: interleaved A/B of the persistent tile loop
         for lay, shapes in SHAPES.items():
             for (M, N, Kd) in shapes:
