@@ -44,8 +44,10 @@ enum {
 
 int mm_version(void);
 const char* mm_error_string(int code);
-/* tuning / A-B switches (benchmarks): "gemm_persist" 0|1, "gemm_kernel" 0 auto | 1 v1 | 2 dma256x128 | 3 dma256x256 */
+/* tuning / A-B switches (benchmarks): "gemm_persist" 0|1, "gemm_kernel" 0 auto | 1 v1 | 2 dma256x128 | 3 dma256x256,
+ * "gemm_issue_waves" 2|4|8, "attn_issue_waves" 4|8 (how many of a workgroup's 8 waves issue the LDS-DMA)           */
 int mm_set_option(const char* name, int value);
+int mm_attn_set_issue_waves(int v);
 
 /* ---- GEMM: every nn.Linear / Conv2d(k=s) on the path -------------------------------------
  * replaces F.linear in mlp.py:33-39, HF:clip:280-384 (q/k/v/out/fc1/fc2), HF:clip:152-158 (patch conv as

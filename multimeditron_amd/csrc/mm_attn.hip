@@ -656,6 +656,7 @@ __device__ __forceinline__ void imgb_dma(unsigned tile_lds, const SRsrc& rs, int
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int PPW = ROWS / (4 * NW);
   static_assert(PPW >= 1, "tile too small for this many waves");
+  if (w >= NW) return;      // NW < waves in the workgroup: only the first NW waves issue (staggers SIMD partners)
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int pc = w * PPW + i;
@@ -688,6 +689,7 @@ __device__ __forceinline__ SRsrc rows_rsrc(const bf16* base, int nrows, int64_t 
   return make_srsrc(base, nrows > 0 ? ((int64_t)(nrows - 1) * stride + 128) * 2 : 0);
 }
 
+template <int INW>
 __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
   constexpr int BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
@@ -722,8 +724,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
   }
   auto issue = [&](int t) {
     const unsigned st = lds0 + (unsigned)((t & 1) * 2 * TILE);
-    imgb_dma<BKV>(st, rk, a.k_ss, t * BKV);
-    imgb_dma<BKV>(st + TILE, rv, a.v_ss, t * BKV);
+    imgb_dma<BKV, INW>(st, rk, a.k_ss, t * BKV);
+    imgb_dma<BKV, INW>(st + TILE, rv, a.v_ss, t * BKV);
   };
   if (ntiles > 0) issue(0);
   for (int t = 0; t < ntiles; ++t) {
@@ -944,6 +946,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv128_kernel(AttnArgs a) {
 
 // dQ for D = 128: same shape as the forward fast path (8 waves, 256 query rows, K/V tiles by LDS-DMA, one barrier per
 // tile).  The single K image serves the row fragments of S^T = K.Q^T and the transposed fragments of dQ^T += K^T.dS^T.
+template <int INW>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq128_kernel(AttnArgs a) {
   constexpr int BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
@@ -987,8 +990,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq128_kernel(AttnArgs a) {
   }
   auto issue = [&](int t) {
     const unsigned st = lds0 + (unsigned)((t & 1) * 2 * TILE);
-    imgb_dma<BKV>(st, rk, a.k_ss, t * BKV);
-    imgb_dma<BKV>(st + TILE, rv, a.v_ss, t * BKV);
+    imgb_dma<BKV, INW>(st, rk, a.k_ss, t * BKV);
+    imgb_dma<BKV, INW>(st + TILE, rv, a.v_ss, t * BKV);
   };
   if (ntiles > 0) issue(0);
   for (int t = 0; t < ntiles; ++t) {
@@ -1050,6 +1053,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq128_kernel(AttnArgs a) {
   }
 }
 
+int g_attn_issue_waves = 4;   // waves issuing the K/V DMA in the 8-wave D=128 kernels (mm_set_option "attn_issue_waves")
+
 static bool attn_use_v1() {
   static const bool v1 = [] { const char* e = getenv("MM_ATTN_KERNEL"); return e && e[0] == 'v'; }();
   return v1;
@@ -1060,8 +1065,13 @@ int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
   if (D == 128 && !attn_use_v1()) {
     const size_t lds = 2 * 2 * 64 * 256;
     dim3 grid((a.Sq + 255) / 256, a.Hq, a.B), block(512);
-    (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_fwd128_kernel, grid, block, lds, s, a);
+    if (g_attn_issue_waves == 4) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_fwd128_kernel<4>, grid, block, lds, s, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_fwd128_kernel<8>, grid, block, lds, s, a);
+    }
     return MM_OK;
   }
   const size_t lds = 2 * 64 * D * 2;
@@ -1074,8 +1084,13 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
   if (D == 128 && !attn_use_v1()) {
     const size_t lds = 2 * 2 * 64 * 256;
     dim3 grid((a.Sq + 255) / 256, a.Hq, a.B), block(512);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_dq128_kernel, grid, block, lds, s, a);
+    if (g_attn_issue_waves == 4) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_dq128_kernel<4>, grid, block, lds, s, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_dq128_kernel<8>, grid, block, lds, s, a);
+    }
   } else {
     const size_t lds = 3 * 64 * D * 2;
     dim3 grid((a.Sq + 127) / 128, a.Hq, a.B), block(256);
@@ -1095,6 +1110,12 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int mm_attn_set_issue_waves(int v) {
+  if (v != 4 && v != 8) return MM_ERR_ARG;
+  g_attn_issue_waves = v;
+  return MM_OK;
+}
 
 static int check_common(int dtype, int B, int Sq, int Skv, int Hq, int Hkv, int D) {
   if (B < 0 || Sq < 0 || Skv < 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || D <= 0) return MM_ERR_ARG;

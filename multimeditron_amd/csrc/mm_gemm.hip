@@ -583,8 +583,11 @@ static int g_opt_persist = 1;   // walk tiles with resident workgroups
 static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2 dma 256x128, 3 dma 256x256
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
 
+extern "C" int mm_attn_set_issue_waves(int v);
+
 extern "C" int mm_set_option(const char* name, int value) {
   if (!name) return MM_ERR_ARG;
+  if (!strcmp(name, "attn_issue_waves")) return mm_attn_set_issue_waves(value);
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 2 && value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 3) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }

@@ -33,6 +33,11 @@ def run(B, S, Hq, Hkv, D, causal):
     print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} D={D} causal={causal}: fwd {tf:.3f} ms ({f / tf / 1e9:.0f} TF/s)  bwd {tb:.3f} ms ({2.5 * f / tb / 1e9:.0f} TF/s algorithmic)", flush=True)
 
 
+from multimeditron_amd._lib import lib
+for nw in (8, 4, 8, 4):
+    lib().mm_set_option(b"attn_issue_waves", nw)
+    print("attn_issue_waves", nw)
+    run(4, 2048, 32, 8, 128, True)
 run(4, 2048, 32, 8, 128, True)
 run(4, 257, 16, 16, 64, False)
 run(2, 4096, 32, 8, 128, True)
