@@ -1,6 +1,8 @@
 // Fused AdamW over flat parameter storage + global grad-norm (clip) -- replaces the reference's
 // HF-Trainer/DeepSpeed CPU-offloaded Adam (config_alignment.yaml:38-59, deepspeed.json:5-23) with one
 // HBM-bound pass: 16 B/param read (p-master, m, v f32 + g) and 14 B/param written.
+#include <stdlib.h>
+
 #include "mm_common.h"
 
 namespace {
@@ -35,22 +37,63 @@ __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* parti
   }
 }
 
-template <typename T>
+// 4 parameters per thread (16-byte f32 vectors), non-temporal loads/stores: the update streams 30 B/param once and
+// must not evict the GEMM operand panels from L2 while it runs under the next step's forward on a side stream.
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void adamw_kernel(T* p, const T* g, float* master, float* m, float* v, int64_t n, float lr, float b1,
                                                     float b2, float eps, float wd, float bc1, float bc2, const float* clip) {
   const float c = clip ? clip[1] : 1.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = to_f32(g[i]) * c;
-    float w = master[i];
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    w = w * (1.f - lr * wd);
-    w = w - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
-    m[i] = mi;
-    v[i] = vi;
-    master[i] = w;
-    p[i] = from_f32<T>(w);
+  const int64_t nv = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const f32x4 w4 = NT ? __builtin_nontemporal_load((const f32x4*)master + i) : ((const f32x4*)master)[i];
+    const f32x4 m4 = NT ? __builtin_nontemporal_load((const f32x4*)m + i) : ((const f32x4*)m)[i];
+    const f32x4 v4 = NT ? __builtin_nontemporal_load((const f32x4*)v + i) : ((const f32x4*)v)[i];
+    float gi[4];
+    if constexpr (sizeof(T) == 2) {
+      const bf16x4 g4 = NT ? __builtin_nontemporal_load((const bf16x4*)g + i) : ((const bf16x4*)g)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gi[k] = (float)g4[k] * c;
+    } else {
+      const f32x4 g4 = NT ? __builtin_nontemporal_load((const f32x4*)g + i) : ((const f32x4*)g)[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gi[k] = g4[k] * c;
+    }
+    f32x4 wo, mo, vo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float mi = b1 * m4[k] + (1.f - b1) * gi[k];
+      const float vi = b2 * v4[k] + (1.f - b2) * gi[k] * gi[k];
+      float w = w4[k] * (1.f - lr * wd);
+      w = w - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+      mo[k] = mi; vo[k] = vi; wo[k] = w;
+    }
+    if (NT) {
+      __builtin_nontemporal_store(mo, (f32x4*)m + i);
+      __builtin_nontemporal_store(vo, (f32x4*)v + i);
+      __builtin_nontemporal_store(wo, (f32x4*)master + i);
+    } else {
+      ((f32x4*)m)[i] = mo;
+      ((f32x4*)v)[i] = vo;
+      ((f32x4*)master)[i] = wo;
+    }
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 po;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) po[k] = (bf16)wo[k];
+      *((bf16x4*)p + i) = po;          // the parameters ARE re-read soon (next forward): default cache policy
+    } else {
+      *((f32x4*)p + i) = wo;
+    }
   }
+  if (blockIdx.x == 0)
+    for (int64_t i = nv * 4 + threadIdx.x; i < n; i += 256) {
+      const float gi = to_f32(g[i]) * c;
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      float w = master[i] * (1.f - lr * wd);
+      w = w - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+      m[i] = mi; v[i] = vi; master[i] = w; p[i] = from_f32<T>(w);
+    }
 }
 
 }  // namespace
@@ -78,11 +121,17 @@ extern "C" int mm_adamw_step(int dtype, void* p, const void* g, float* master, f
   if (!p || !g || !master || !m || !v || n < 0 || step < 1) return MM_ERR_ARG;
   if (n == 0) return MM_OK;
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-  const unsigned nb = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  if (dtype == MM_BF16)
-    hipLaunchKernelGGL(adamw_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (bf16*)p, (const bf16*)g, master, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, clip);
-  else
-    hipLaunchKernelGGL(adamw_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (float*)p, (const float*)g, master, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, clip);
+  if (!mm_aligned16(p) || !mm_aligned16(g) || !mm_aligned16(master) || !mm_aligned16(m) || !mm_aligned16(v)) return MM_ERR_ALIGN;
+  const int64_t nv4 = (n / 4 + 255) / 256;
+  const unsigned nb = (unsigned)(nv4 < 1 ? 1 : (nv4 < 2048 ? nv4 : 2048));
+  static const bool nt = [] { const char* e = getenv("MM_ADAMW_NT"); return !e || e[0] != '0'; }();
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MM_BF16) {
+    if (nt) hipLaunchKernelGGL((adamw_kernel<bf16, true>), dim3(nb), dim3(256), 0, st, (bf16*)p, (const bf16*)g, master, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, clip);
+    else hipLaunchKernelGGL((adamw_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, (bf16*)p, (const bf16*)g, master, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, clip);
+  } else {
+    hipLaunchKernelGGL((adamw_kernel<float, false>), dim3(nb), dim3(256), 0, st, (float*)p, (const float*)g, master, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, clip);
+  }
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
