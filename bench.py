@@ -101,7 +101,7 @@ def measure_gemm_roofline(trainer, batch):
                 achieved_tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0, gemm_ms_per_step=tot_ms)
 
 
-def cpu_baseline(llm, vis, hidden, workload, budget_layers=4, S=1024, B=2):
+def cpu_baseline(llm, vis, hidden, workload, budget_layers=8, S=1024, B=2):
     """The CPU oracle (torch CPU ops, the restatement of the reference's HF path) on a bounded slice of the workload:
     the 8B-shaped decoder truncated to `budget_layers` layers + ViT truncated likewise + projector + full lm_head, B=1,
     fwd+bwd in bf16 (the reference trains under torch.set_default_dtype(bfloat16)); converted to equivalent samples/s of the

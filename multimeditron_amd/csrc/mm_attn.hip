@@ -902,12 +902,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv128_kernel(AttnArgs a) {
       }
       __builtin_amdgcn_s_setprio(0);
       bf16x8 pf[2], dsf[2];
+      // masks only where they can bite: a padded/out-of-range key in this wave, or a tile that touches the diagonal
+      const bool need_mask = (__ballot(kvalid) != ~0ull) || (a.causal && (k0 + 31) > (qb + shift));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = acc_row(r, h);
-        bool ok = kvalid;
-        if (a.causal) ok = ok && ki <= (qb + ql + shift);
-        const float p = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], sc, -rcs[ql])) : 0.f;
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], sc, -rcs[ql]));
+        if (need_mask) {
+          bool ok = kvalid;
+          if (a.causal) ok = ok && ki <= (qb + ql + shift);
+          p = ok ? p : 0.f;
+        }
         const float dsv = p * (dp_acc[r] - rcs[32 + ql]) * a.scale;
         pf[r >> 3][r & 7] = (bf16)p;
         dsf[r >> 3][r & 7] = (bf16)dsv;
