@@ -8,7 +8,7 @@ import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(_PKG, "..", "include", "mm_hip.h")
-LIB_PATH = os.path.join(_PKG, "libmmhip.so")
+LIB_PATH = os.environ.get("MM_HIP_LIBRARY") or os.path.join(_PKG, "libmmhip.so")   # override: kernel experiments only
 
 MM_BF16, MM_F32 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2

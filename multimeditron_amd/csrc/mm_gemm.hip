@@ -314,6 +314,9 @@ __device__ __forceinline__ void lds_dma16xN(const SRsrc& r, const unsigned (&vof
 // descriptor of one operand anchored at the tile origin (k = 0); built once per workgroup
 template <bool KC>
 __device__ __forceinline__ SRsrc tile_rsrc(const bf16* base, int ld, int x0, int Xtot, int Ktot) {
+#ifdef MM_GEMM_DIAG_OOB
+  return make_srsrc(base, 0);   // timing experiment: every DMA lane out of range (zeros land in LDS, no memory traffic)
+#endif
   if constexpr (KC) return make_srsrc(base + (int64_t)x0 * ld, (int64_t)(Xtot - x0) * ld * 2);
   else return make_srsrc(base + x0, ((int64_t)Ktot * ld - x0) * 2);
 }
@@ -349,6 +352,68 @@ __device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld,
     }
     lds_dma16xN<PER, NW * 1024>(rs, offs, tile + (w + NW * c * PER) * 1024);
   }
+}
+
+// ---- loop-invariant form of dma_tile: the per-lane offsets of a wave's pieces do not depend on the K-step (the
+// descriptor is anchored at the tile origin), so they are computed ONCE per workgroup and the K-step enters through the
+// instruction's SGPR soffset (k0*2 bytes for a K-contiguous operand, k0*ld*2 for a K-strided one).  soffset is not part
+// of the hardware range check, so this form is only used for K-steps that lie wholly inside K (the ragged last step
+// goes through dma_tile, whose offsets carry the K bound).
+template <bool KC, int XR, int NW>
+__device__ __forceinline__ void dma_offsets(unsigned (&offs)[XR / (8 * NW)], int ld) {
+  const int l = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int PPW = XR / (8 * NW);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = w + NW * i;
+    if constexpr (KC) {
+      const int row = pc * 8 + (l >> 3);
+      const int kc = (l & 7) ^ kc_swz(row);
+      offs[i] = (unsigned)(row * ld + kc * 8) * 2u;
+    } else {
+      constexpr int SPR = XR / 8, RPP = 64 / SPR;
+      const int k = pc * RPP + l / SPR;
+      const int sl = l % SPR;
+      const int c32 = ((sl >> 1) - ks_swz(k)) & (XR / 16 - 1);
+      offs[i] = ((unsigned)k * (unsigned)ld + (unsigned)(c32 * 16 + (sl & 1) * 8)) * 2u;
+    }
+  }
+}
+
+template <int STEP>
+__device__ __forceinline__ void lds_dma16x4s(const SRsrc& r, unsigned v0, unsigned v1, unsigned v2, unsigned v3,
+                                             unsigned lds_addr0, unsigned soff) {
+  u32x4 d = {r.w0, r.w1, r.w2, r.w3};
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %1, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, %7\n\t"
+      "buffer_load_dwordx4 %2, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, %7\n\t"
+      "buffer_load_dwordx4 %3, %6, %8 offen lds\n\t"
+      "s_add_u32 m0, m0, %7\n\t"
+      "buffer_load_dwordx4 %4, %6, %8 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_addr0), "s"(d), "i"(STEP), "s"(soff)
+      : "memory", "scc");
+}
+
+template <int XR, int NW>
+__device__ __forceinline__ void dma_tile_inv(unsigned tile, const SRsrc& rs, const unsigned (&offs)[XR / (8 * NW)],
+                                             unsigned soff) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int PPW = XR / (8 * NW);
+  static_assert(PPW % 4 == 0, "pieces per wave");
+  if (w >= NW) return;
+#pragma unroll
+  for (int c = 0; c < PPW / 4; ++c)
+    lds_dma16x4s<NW * 1024>(rs, offs[4 * c], offs[4 * c + 1], offs[4 * c + 2], offs[4 * c + 3],
+                            tile + (w + NW * c * 4) * 1024, soff);
 }
 
 template <bool KC, int XR>
@@ -398,8 +463,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   int m0 = pm * BM_, n0 = pn * BN_;
   SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
   SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
+  constexpr bool INV = (BM_ / (8 * ISSUE_WAVES)) % 4 == 0 && (BN_ / (8 * ISSUE_WAVES)) % 4 == 0;
+  unsigned offa[INV ? BM_ / (8 * ISSUE_WAVES) : 1], offb[INV ? BN_ / (8 * ISSUE_WAVES) : 1];
+  if constexpr (INV) {
+    dma_offsets<A_KC, BM_, ISSUE_WAVES>(offa, g.lda);
+    dma_offsets<B_KC, BN_, ISSUE_WAVES>(offb, g.ldb);
+  }
+  const int nk_full = g.K / G_BK;                                     // K-steps wholly inside K
+  const unsigned sa = A_KC ? (unsigned)(G_BK * 2) : (unsigned)(G_BK * 2) * (unsigned)g.lda;   // soffset per K-step
+  const unsigned sb = B_KC ? (unsigned)(G_BK * 2) : (unsigned)(G_BK * 2) * (unsigned)g.ldb;
   auto issue = [&](const SRsrc& da, const SRsrc& db, int t, int stage) {
     const unsigned st = lds0 + (unsigned)(stage * STAGE_BYTES);
+    if constexpr (INV) {
+      if (t < nk_full) {
+        dma_tile_inv<BM_, ISSUE_WAVES>(st, da, offa, (unsigned)t * sa);
+        dma_tile_inv<BN_, ISSUE_WAVES>(st + A_BYTES, db, offb, (unsigned)t * sb);
+        return;
+      }
+    }
     dma_tile<A_KC, BM_, ISSUE_WAVES>(st, da, g.lda, t * G_BK, g.K);
     dma_tile<B_KC, BN_, ISSUE_WAVES>(st + A_BYTES, db, g.ldb, t * G_BK, g.K);
   };
@@ -424,10 +505,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
       nrb = tile_rsrc<B_KC>(B, g.ldb, nn0, g.N, g.K);
     }
     for (int t = 0; t < nk; ++t, ++sidx) {
+#ifndef MM_GEMM_DIAG_NOWAIT
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       __builtin_amdgcn_s_barrier();
       const char* cur = smem + (sidx & 1) * STAGE_BYTES;
-#ifndef MM_GEMM_LATE_DMA
+#if defined(MM_GEMM_DIAG_NODMA)
+#elif defined(MM_GEMM_DIAG_HOTK)
+      if (t + 1 < nk) issue(ra, rb, 0, (sidx + 1) & 1);
+      else if (next < total) issue(ra, rb, 0, (sidx + 1) & 1);
+#elif !defined(MM_GEMM_LATE_DMA)
       if (t + 1 < nk) issue(ra, rb, t + 1, (sidx + 1) & 1);
       else if (next < total) issue(nra, nrb, 0, (sidx + 1) & 1);
 #endif

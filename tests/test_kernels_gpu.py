@@ -132,6 +132,45 @@ def test_gemm_layouts(K, dtype, layout, shape):
     assert rel(out.float(), ref) < TOL[dtype]
 
 
+DMA_SHAPES = [(256, 256, 64), (300, 520, 192), (1028, 1024, 640), (129, 72, 1088), (513, 264, 200), (2048, 512, 2056),
+              (64, 130, 72)]
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("shape", DMA_SHAPES)
+def test_gemm_dma_kernels_forced(K, variant, layout, shape):
+    """The LDS-DMA kernels (256x128 and 256x256 tiles) are normally chosen only for chip-filling problems; force them
+    on ragged shapes (M, N edges, K not a multiple of the 64-wide K-step, single-tile grids)."""
+    from multimeditron_amd._lib import lib
+    M, N, Kd = shape
+    dtype = torch.bfloat16
+    pad8 = lambda n: (n + 7) // 8 * 8
+    a = rnd((M, Kd), dtype, 1)
+    b = rnd((N, Kd), dtype, 2)
+    ref = a.float() @ b.float().t()
+
+    def padded(x):   # row stride must be a multiple of 8 elements
+        r, c = x.shape
+        o = torch.zeros(r, pad8(c), dtype=dtype)
+        o[:, :c] = x
+        return o.cuda()[:, :c]
+    if layout == "NT":
+        A, B, lay = padded(a), padded(b), 0
+    elif layout == "NN":
+        A, B, lay = padded(a), padded(b.t().contiguous()), 1
+    else:
+        A, B, lay = padded(a.t().contiguous()), padded(b.t().contiguous()), 2
+    assert lib().mm_set_option(b"gemm_kernel", variant) == 0
+    try:
+        out = K.gemm(lay, A, B, M, N, Kd, ldc_pad=True)
+        torch.cuda.synchronize()
+    finally:
+        assert lib().mm_set_option(b"gemm_kernel", 0) == 0
+    assert out.shape == (M, N)
+    assert rel(out.float(), ref) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_asymmetric_identity(K, dtype):
     # A = I with an asymmetric B catches a transposed C write or a permuted fragment map
