@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "mm_common.h"
+#include <string.h>
 
 namespace {
 
@@ -666,6 +667,21 @@ __device__ __forceinline__ void imgb_dma(unsigned tile_lds, const SRsrc& rs, int
     lds_dma16(rs, voff, tile_lds + pc * 1024);
   }
 }
+// same, issued by the NW waves of one TEAM: wt = this wave's index inside its team
+template <int ROWS, int NW>
+__device__ __forceinline__ void imgb_dma_team(unsigned tile_lds, const SRsrc& rs, int64_t stride, int row0, int wt) {
+  const int l = threadIdx.x & 63;
+  constexpr int PPW = ROWS / (4 * NW);
+  static_assert(PPW >= 1, "tile too small for this many waves");
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = wt * PPW + i;
+    const int row = pc * 4 + (l >> 4);
+    const int ch = (l & 15) ^ imgb_swz(row);
+    const unsigned voff = (unsigned)(((int64_t)(row0 + row) * stride) * 2 + ch * 16);
+    lds_dma16(rs, voff, tile_lds + pc * 1024);
+  }
+}
 // row fragment (32 rows x 16 k): lane row = r0 + (l&31), k = kstep*16 + 8*(l>>5) .. +7
 __device__ __forceinline__ bf16x8 imgb_rowfrag(const char* tile, int r0, int kstep) {
   const int l = threadIdx.x & 63;
@@ -689,13 +705,36 @@ __device__ __forceinline__ SRsrc rows_rsrc(const bf16* base, int nrows, int64_t 
   return make_srsrc(base, nrows > 0 ? ((int64_t)(nrows - 1) * stride + 128) * 2 : 0);
 }
 
+// Work order of the D = 128 kernels (1-D grid).  Under a causal mask a block's work grows with its position, and the
+// hardware hands out workgroups in index order: with the heaviest blocks LAST the launch ends on a few long workgroups
+// (62 vs 40 tile-times for 8 blocks x 128 heads on 512 slots).  Heaviest first fixes that.  Workgroup ids that are
+// congruent mod 8 share an XCD (and its L2): the query heads of one key/value head are given consecutive turns on ONE
+// XCD so its K/V rows are fetched into that L2 once per group.
+__device__ __forceinline__ void attn_work_item(int id, int nblk, int B, int Hq, int Hkv, bool heavy_last, int& blk, int& b,
+                                               int& hq) {
+  const int nbh = B * Hq, G = Hq / Hkv;
+  const int x = id / nbh, r = id % nbh;
+  blk = heavy_last ? nblk - 1 - x : x;
+  if (((B * Hkv) & 7) == 0) {
+    const int xcd = r & 7, c = r >> 3;
+    const int slot = xcd + 8 * (c / G), g = c % G;     // slot = b * Hkv + hkv
+    b = slot / Hkv;
+    hq = (slot % Hkv) * G + g;
+  } else {
+    b = r / Hq;
+    hq = r % Hq;
+  }
+}
+
 template <int INW>
 __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
   constexpr int BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
-  const int b = blockIdx.z, hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
-  const int q0 = blockIdx.x * 256 + w * 32;
+  int qblk, b, hq;
+  attn_work_item(blockIdx.x, (a.Sq + 255) / 256, a.B, a.Hq, a.Hkv, a.causal != 0, qblk, b, hq);
+  const int hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = qblk * 256 + w * 32;
   const int qi = q0 + (l & 31);
   const int shift = a.Skv - a.Sq;
   const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
@@ -719,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
 
   int ntiles = (a.Skv + BKV - 1) / BKV;
   if (a.causal) {
-    const int qmax = min(a.Sq - 1, (int)blockIdx.x * 256 + 255) + shift;
+    const int qmax = min(a.Sq - 1, qblk * 256 + 255) + shift;
     ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
   }
   auto issue = [&](int t) {
@@ -732,7 +771,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
     const int kv0 = t * BKV;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifndef MM_ATTN_DIAG_FWD_NODMA
     if (t + 1 < ntiles) issue(t + 1);
+#endif
     // wave-uniform skip: this wave's rows are all beyond Sq, or the whole tile lies above its causal diagonal
     if (q0 >= a.Sq || (a.causal && kv0 > q0 + 31 + shift)) continue;
     const char* Kt = smem + (t & 1) * 2 * TILE;
@@ -748,12 +789,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+#ifdef MM_ATTN_DIAG_FWD_NOQK
+      s_acc[kb] = o_acc[kb];
+#else
 #pragma unroll
       for (int ds = 0; ds < NDS; ++ds)
         s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_rowfrag(Kt, kb * 32, ds), qf[ds], s_acc[kb], 0, 0, 0);
+#endif
     }
     __builtin_amdgcn_s_setprio(0);
     float mx = -INFINITY;
+#ifdef MM_ATTN_DIAG_FWD_NOSM
+    bf16x8 pf[2][2];
+    float alpha = 1.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (bf16)s_acc[kb][r];
+    if (need_mask) l_run += 1.f;
+#else
     if (need_mask) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -788,6 +842,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
       }
     l_run = l_run * alpha + rs;
     m_run = m_new;
+#endif
+#ifdef MM_ATTN_DIAG_FWD_NOPV
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[r & 3][r] = o_acc[r & 3][r] * alpha + (float)pf[r & 1][(r >> 3) & 1][r & 7] + (float)pf[(r + 1) & 1][(r >> 3) & 1][r & 7];
+#else
 #pragma unroll
     for (int db = 0; db < NDB; ++db) {
 #pragma unroll
@@ -800,6 +859,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
           o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_tfrag(Vt, db, kb * 32 + s * 16), pf[kb][s], o_acc[db], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
+#endif
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -949,6 +1009,179 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv128_kernel(AttnArgs a) {
   }
 }
 
+// dK/dV for D = 128, balanced form (used when the GQA group size is even).  Under a causal mask key block j meets
+// (nkb - j) query blocks, a 16:1 spread at S = 2048, and with B*Hkv*nkb = 512 items on 512 workgroup slots the launch
+// lasts as long as block 0.  Here ONE workgroup of 8 waves owns the PAIR of key blocks (j, nkb-1-j), processed one after
+// the other, so every workgroup does the same (nkb+1) block-units; its two 4-wave teams split the query heads of the
+// group (team t: heads t*G/2 ..), each with its own Q/dO ring, and their dK/dV accumulators are summed through LDS at
+// the end of a block (fixed order: deterministic, no atomics, no global partials).  One workgroup per CU, 2 waves/SIMD.
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pair_kernel(AttnArgs a) {
+  constexpr int BQ = 32, NDS = 8, NDB = 4, QT = BQ * 256;            // 8 KiB per 32-row tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Vimg = smem;                                                   // 128 keys x 256 B
+  const int l = threadIdx.x & 63, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: LDS-DMA addresses live in SGPRs
+  const int team = w >> 2, wt = w & 3, tt = threadIdx.x & 255;
+  char* ring = smem + 128 * 256 + team * 4 * QT;                       // per team [2 stages][Q 8 KiB | dO 8 KiB]
+  float* red = (float*)(smem + 128 * 256);                             // 64 KiB = both rings, reused for the team sum
+  float* rowc = (float*)(smem + 128 * 256 + 8 * QT) + team * 128;      // per team [2 stages][lse*log2e (32) | delta (32)]
+  const int b = blockIdx.z, hkv = blockIdx.y;
+  const int G = a.Hq / a.Hkv, GH = G / 2;
+  const int nkb = (a.Skv + 127) / 128;
+  const int shift = a.Skv - a.Sq;
+  const bf16* K = (const bf16*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const unsigned ring0 = lds0 + 128 * 256 + (unsigned)(team * 4 * QT);
+  const float sc = a.scale * LOG2E;
+  const int nqt = (a.Sq + BQ - 1) / BQ;
+  const int64_t do_ss = (int64_t)a.Hq * 128;
+
+  for (int pass = 0; pass < 2; ++pass) {
+    const int kb = pass == 0 ? (int)blockIdx.x : nkb - 1 - (int)blockIdx.x;
+    if (pass == 1 && kb <= (int)blockIdx.x) break;                    // odd count: the middle block has no partner
+    const int kblk = kb * 128;
+    const int k0 = kblk + wt * 32;
+    const int ki = k0 + (l & 31);
+    {
+      const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+      imgb_dma<128, 8>(lds0, rv, a.v_ss, kblk);
+    }
+    bf16x8 kf[NDS];
+    {
+      const bf16* krow = ki < a.Skv ? K + (int64_t)ki * a.k_ss : nullptr;
+#pragma unroll
+      for (int ds = 0; ds < NDS; ++ds) kf[ds] = row_frag_global(krow, ds);
+    }
+    bool kvalid = ki < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + ki] != 0;
+    f32x16 dk_acc[NDB], dv_acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk_acc[i][r] = 0.f; dv_acc[i][r] = 0.f; }
+
+    int qt0 = 0;
+    if (a.causal) qt0 = max(0, kblk - shift) / BQ;
+    const int per_head = max(0, nqt - qt0);
+    const int niter = per_head * GH;                                   // the same count for both teams
+    float rc = 0.f;
+    auto issue = [&](int it) {
+      const int g = team * GH + it / per_head, qb = (qt0 + it % per_head) * BQ;
+      const int hq = hkv * G + g;
+      const SRsrc rq = rows_rsrc((const bf16*)a.q + b * a.q_sb + hq * a.q_sh, a.Sq, a.q_ss);
+      const SRsrc rdo = rows_rsrc((const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128, a.Sq, do_ss);
+      const unsigned st = ring0 + (unsigned)((it & 1) * 2 * QT);
+      imgb_dma_team<BQ, 4>(st, rq, a.q_ss, qb, wt);
+      imgb_dma_team<BQ, 4>(st + QT, rdo, do_ss, qb, wt);
+      if (tt < 64) {
+        const int qq = qb + (tt & 31);
+        const int64_t ro = ((int64_t)b * a.Hq + hq) * a.Sq + qq;
+        if (tt < 32) rc = qq < a.Sq ? a.lse[ro] * LOG2E : INFINITY;
+        else rc = qq < a.Sq ? a.delta[ro] : 0.f;
+      }
+    };
+    if (niter > 0) {
+      issue(0);
+      if (tt < 64) rowc[tt] = rc;
+    }
+    for (int it = 0; it < niter; ++it) {
+      const int qb = (qt0 + it % per_head) * BQ;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (it + 1 < niter) issue(it + 1);
+      const char* Qt = ring + (it & 1) * 2 * QT;
+      const char* Ot = Qt + QT;
+      const float* rcs = rowc + (it & 1) * 64;
+      if (!(a.causal && k0 > qb + BQ - 1 + shift)) {
+        f32x16 s_acc, dp_acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+          s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_rowfrag(Qt, 0, ds), kf[ds], s_acc, 0, 0, 0);
+          dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_rowfrag(Ot, 0, ds), imgb_rowfrag(Vimg, wt * 32, ds), dp_acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        bf16x8 pf[2], dsf[2];
+        const bool need_mask = (__ballot(kvalid) != ~0ull) || (a.causal && (k0 + 31) > (qb + shift));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = acc_row(r, h);
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], sc, -rcs[ql]));
+          if (need_mask) {
+            bool ok = kvalid;
+            if (a.causal) ok = ok && ki <= (qb + ql + shift);
+            p = ok ? p : 0.f;
+          }
+          const float dsv = p * (dp_acc[r] - rcs[32 + ql]) * a.scale;
+          pf[r >> 3][r & 7] = (bf16)p;
+          dsf[r >> 3][r & 7] = (bf16)dsv;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_tfrag(Ot, db, s * 16), pf[s], dv_acc[db], 0, 0, 0);
+            dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(imgb_tfrag(Qt, db, s * 16), dsf[s], dk_acc[db], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      if (it + 1 < niter && tt < 64) rowc[((it + 1) & 1) * 64 + tt] = rc;
+    }
+    // ---- sum the two teams' accumulators through LDS (team 1 writes, team 0 adds: fixed order), then team 0 stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                   // every wave has left the rings and the V image
+    float* mine = red + (wt * 64) * 64 + l;                            // [wave-in-team][64 values][lane]
+    if (team == 1) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(db * 16 + r) * 64] = dk_acc[db][r];
+    }
+    __syncthreads();
+    if (team == 0) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk_acc[db][r] += mine[(db * 16 + r) * 64];
+    }
+    __syncthreads();
+    if (team == 1) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(db * 16 + r) * 64] = dv_acc[db][r];
+    }
+    __syncthreads();
+    if (team == 0) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv_acc[db][r] += mine[(db * 16 + r) * 64];
+      if (ki < a.Skv) {
+        bf16* dkrow = (bf16*)a.dk + b * a.k_sb + hkv * a.k_sh + (int64_t)ki * a.k_ss;
+        bf16* dvrow = (bf16*)a.dv + b * a.v_sb + hkv * a.v_sh + (int64_t)ki * a.v_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            bf16x4 ok_, ov_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ok_[e] = (bf16)dk_acc[db][rg * 4 + e];
+              ov_[e] = (bf16)dv_acc[db][rg * 4 + e];
+            }
+            *(bf16x4*)(dkrow + db * 32 + 8 * rg + 4 * h) = ok_;
+            *(bf16x4*)(dvrow + db * 32 + 8 * rg + 4 * h) = ov_;
+          }
+      }
+    }
+    __syncthreads();                                                   // `red` is free again before the next pass's DMA
+  }
+}
+
 // dQ for D = 128: same shape as the forward fast path (8 waves, 256 query rows, K/V tiles by LDS-DMA, one barrier per
 // tile).  The single K image serves the row fragments of S^T = K.Q^T and the transposed fragments of dQ^T += K^T.dS^T.
 template <int INW>
@@ -956,8 +1189,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq128_kernel(AttnArgs a) {
   constexpr int BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
-  const int b = blockIdx.z, hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
-  const int q0 = blockIdx.x * 256 + w * 32;
+  int qblk, b, hq;
+  attn_work_item(blockIdx.x, (a.Sq + 255) / 256, a.B, a.Hq, a.Hkv, a.causal != 0, qblk, b, hq);
+  const int hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = qblk * 256 + w * 32;
   const int qi = q0 + (l & 31);
   const int shift = a.Skv - a.Sq;
   const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
@@ -990,7 +1225,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq128_kernel(AttnArgs a) {
 
   int ntiles = (a.Skv + BKV - 1) / BKV;
   if (a.causal) {
-    const int qmax = min(a.Sq - 1, (int)blockIdx.x * 256 + 255) + shift;
+    const int qmax = min(a.Sq - 1, qblk * 256 + 255) + shift;
     ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
   }
   auto issue = [&](int t) {
@@ -1058,6 +1293,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq128_kernel(AttnArgs a) {
   }
 }
 
+int g_attn_dkv_pair = 1;      // balanced paired dK/dV kernel (mm_set_option "attn_dkv_pair"; 0 = one key block per workgroup)
 int g_attn_issue_waves = 4;   // waves issuing the K/V DMA in the 8-wave D=128 kernels (mm_set_option "attn_issue_waves")
 
 static bool attn_use_v1() {
@@ -1069,7 +1305,9 @@ template <int D>
 int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
   if (D == 128 && !attn_use_v1()) {
     const size_t lds = 2 * 2 * 64 * 256;
-    dim3 grid((a.Sq + 255) / 256, a.Hq, a.B), block(512);
+    const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;     // 1-D grid: attn_work_item orders the blocks
+    if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+    dim3 grid((unsigned)nwg), block(512);
     if (g_attn_issue_waves == 4) {
       (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(attn_fwd128_kernel<4>, grid, block, lds, s, a);
@@ -1088,7 +1326,9 @@ template <int D>
 int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
   if (D == 128 && !attn_use_v1()) {
     const size_t lds = 2 * 2 * 64 * 256;
-    dim3 grid((a.Sq + 255) / 256, a.Hq, a.B), block(512);
+    const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;     // 1-D grid: attn_work_item orders the blocks
+    if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+    dim3 grid((unsigned)nwg), block(512);
     if (g_attn_issue_waves == 4) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(attn_bwd_dq128_kernel<4>, grid, block, lds, s, a);
@@ -1102,10 +1342,18 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, block, lds, s, a);
   }
   if (D == 128 && !attn_use_v1()) {
-    const size_t lds = 128 * 256 + 4 * 32 * 256 + 2 * 64 * sizeof(float);
-    dim3 grid((a.Skv + 127) / 128, a.Hkv, a.B), block(256);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_dkv128_kernel, grid, block, lds, s, a);
+    if (((a.Hq / a.Hkv) & 1) == 0 && g_attn_dkv_pair) {
+      const size_t lds = 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);
+      const int nkb = (a.Skv + 127) / 128;
+      dim3 grid((nkb + 1) / 2, a.Hkv, a.B), block(512);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_dkv128_pair_kernel, grid, block, lds, s, a);
+    } else {
+      const size_t lds = 128 * 256 + 4 * 32 * 256 + 2 * 64 * sizeof(float);
+      dim3 grid((a.Skv + 127) / 128, a.Hkv, a.B), block(256);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_dkv128_kernel, grid, block, lds, s, a);
+    }
   } else {
     const size_t lds = 4 * 32 * D * 2 + 64 * sizeof(float);
     dim3 grid((a.Skv + 127) / 128, a.Hkv, a.B), block(256);
@@ -1115,6 +1363,11 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+int mm_attn_option(const char* name, int value) {   // reached through mm_set_option (mm_gemm.hip)
+  if (!strcmp(name, "attn_dkv_pair")) { g_attn_dkv_pair = value != 0; return MM_OK; }
+  return MM_ERR_ARG;
+}
 
 extern "C" int mm_attn_set_issue_waves(int v) {
   if (v != 4 && v != 8) return MM_ERR_ARG;

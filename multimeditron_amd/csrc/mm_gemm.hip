@@ -514,30 +514,42 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
 #elif defined(MM_GEMM_DIAG_HOTK)
       if (t + 1 < nk) issue(ra, rb, 0, (sidx + 1) & 1);
       else if (next < total) issue(ra, rb, 0, (sidx + 1) & 1);
-#elif !defined(MM_GEMM_LATE_DMA)
+#else
       if (t + 1 < nk) issue(ra, rb, t + 1, (sidx + 1) & 1);
       else if (next < total) issue(nra, nrb, 0, (sidx + 1) & 1);
 #endif
+      // 4 phases of (MREP/2 x NREP) MFMAs; the fragments of phase p+1 are requested BEFORE phase p's MFMAs are issued, so
+      // inside a wave the LDS latency of all but the first phase hides under 16 MFMAs (+1.3 % over read-then-multiply).
+      {
+        constexpr int HM = MREP / 2;
+        static_assert(MREP % 2 == 0, "two A halves per k-step");
+        bf16x8 fbq[2][NREP], faq[2][HM];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#ifdef MM_GEMM_LATE_DMA
-        if (ks == 1) {   // experiment: start the MFMAs first, issue the next tile's DMA between the two k-steps
-          if (t + 1 < nk) issue(ra, rb, t + 1, (sidx + 1) & 1);
-          else if (next < total) issue(nra, nrb, 0, (sidx + 1) & 1);
+        for (int j = 0; j < NREP; ++j) fbq[0][j] = frag_load2<B_KC, BN_>(cur + A_BYTES, wn * NREP + j, 0);
+#pragma unroll
+        for (int i = 0; i < HM; ++i) faq[0][i] = frag_load2<A_KC, BM_>(cur, wm * MREP + i, 0);
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          const int ks = ph >> 1, hf = ph & 1;
+          if (ph < 3) {
+            const int nks = (ph + 1) >> 1, nhf = (ph + 1) & 1;
+            if (nhf == 0) {
+#pragma unroll
+              for (int j = 0; j < NREP; ++j) fbq[nks & 1][j] = frag_load2<B_KC, BN_>(cur + A_BYTES, wn * NREP + j, nks);
+            }
+#pragma unroll
+            for (int i = 0; i < HM; ++i) faq[(ph + 1) & 1][i] = frag_load2<A_KC, BM_>(cur, wm * MREP + nhf * HM + i, nks);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < HM; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+              acc[hf * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbq[ks & 1][j], faq[ph & 1][i], acc[hf * HM + i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-#endif
-        bf16x8 fa[MREP], fb[NREP];
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) fb[j] = frag_load2<B_KC, BN_>(cur + A_BYTES, wn * NREP + j, ks);
-#pragma unroll
-        for (int i = 0; i < MREP; ++i) fa[i] = frag_load2<A_KC, BM_>(cur, wm * MREP + i, ks);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
-#pragma unroll
-          for (int j = 0; j < NREP; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
       }
     }
     gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
@@ -671,12 +683,14 @@ static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2 dma
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
 
 extern "C" int mm_attn_set_issue_waves(int v);
+int mm_attn_option(const char* name, int value);
 
 extern "C" int mm_set_option(const char* name, int value) {
   if (!name) return MM_ERR_ARG;
   if (!strcmp(name, "attn_issue_waves")) return mm_attn_set_issue_waves(value);
+  if (!strncmp(name, "attn_", 5)) return mm_attn_option(name, value);
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
-  if (!strcmp(name, "gemm_issue_waves")) { if (value != 2 && value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
+  if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 3) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -725,10 +739,6 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
   do {                                                                                                                   \
     if (variant == 1) {                                                                                                  \
       auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 128, 4, 2, 8>;                                                       \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-      hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
-    } else if (g_opt_issue_waves == 2) {                                                                                 \
-      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 256, 2, 2, 2>;                                                       \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
       hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
     } else if (g_opt_issue_waves == 4) {                                                                                 \

@@ -34,6 +34,17 @@ def run(B, S, Hq, Hkv, D, causal):
 
 
 from multimeditron_amd._lib import lib
+if "--ab-pair" in sys.argv:      # dK/dV: one key block per workgroup vs the balanced paired kernel (same process)
+    for v in (0, 1, 0, 1):
+        lib().mm_set_option(b"attn_dkv_pair", v)
+        print("attn_dkv_pair", v)
+        run(4, 2048, 32, 8, 128, True)
+    run(2, 4096, 32, 8, 128, True)
+    sys.exit(0)
+if "--quick" in sys.argv:
+    run(4, 2048, 32, 8, 128, True)
+    run(4, 2048, 32, 8, 128, True)
+    sys.exit(0)
 for nw in (8, 4, 8, 4):
     lib().mm_set_option(b"attn_issue_waves", nw)
     print("attn_issue_waves", nw)
