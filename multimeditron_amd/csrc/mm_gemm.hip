@@ -644,32 +644,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // few enough (<= 8192) that one block per 32 column groups sweeping all rows with 8 row lanes is HBM-efficient.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, T* out, int accumulate) {
-  constexpr int VN = Vec16<T>::N;
-  __shared__ float red[8][32 * VN + 1];
-  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int n0 = (blockIdx.x * 32 + cg) * VN;
+  // one block = 8 column chunks of 16 B (one 128-B line per row) x 32 row lanes: the bias-gradient inputs are short
+  // (ViT: 1028 rows) and narrow, so parallelism comes from many small blocks and 4 independent loads per lane in flight
+  constexpr int VN = Vec16<T>::N, CG = 8, RL = 32;
+  __shared__ float red[RL][CG * VN + 1];
+  const int cg = threadIdx.x & (CG - 1), rl = threadIdx.x / CG;
+  const int n0 = (blockIdx.x * CG + cg) * VN;
   float acc[VN];
 #pragma unroll
   for (int k = 0; k < VN; ++k) acc[k] = 0.f;
   if (n0 + VN <= N) {
-    for (int m = rl; m < M; m += 8) {
+    int m = rl;
+    for (; m + 3 * RL < M; m += 4 * RL) {
+      Vec16<T> v0 = *(const Vec16<T>*)(X + (int64_t)m * ldx + n0);
+      Vec16<T> v1 = *(const Vec16<T>*)(X + (int64_t)(m + RL) * ldx + n0);
+      Vec16<T> v2 = *(const Vec16<T>*)(X + (int64_t)(m + 2 * RL) * ldx + n0);
+      Vec16<T> v3 = *(const Vec16<T>*)(X + (int64_t)(m + 3 * RL) * ldx + n0);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) acc[k] += (v0.get(k) + v1.get(k)) + (v2.get(k) + v3.get(k));
+    }
+    for (; m < M; m += RL) {
       Vec16<T> v = *(const Vec16<T>*)(X + (int64_t)m * ldx + n0);
 #pragma unroll
       for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
     }
   } else if (n0 < N) {
-    for (int m = rl; m < M; m += 8)
+    for (int m = rl; m < M; m += RL)
       for (int k = 0; k < VN && n0 + k < N; ++k) acc[k] += to_f32(X[(int64_t)m * ldx + n0 + k]);
   }
 #pragma unroll
   for (int k = 0; k < VN; ++k) red[rl][cg * VN + k] = acc[k];
   __syncthreads();
-  for (int c = threadIdx.x; c < 32 * VN; c += 256) {
-    const int n = blockIdx.x * 32 * VN + c;
+  for (int c = threadIdx.x; c < CG * VN; c += 256) {
+    const int n = blockIdx.x * CG * VN + c;
     if (n < N) {
       float t = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) t += red[r][c];
+      for (int r = 0; r < RL; ++r) t += red[r][c];
       if (accumulate) t += to_f32(out[n]);
       out[n] = from_f32<T>(t);
     }
@@ -679,7 +690,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
 }  // namespace
 
 static int g_opt_persist = 1;   // walk tiles with resident workgroups
-static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2 dma 256x128, 3 dma 256x256
+static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2..6 LDS-DMA tiles 256x128, 256x256, 128x128, 64x128, 64x64
+static int g_opt_small = -1;    // experiments: force the DMA variant for problems that do not fill the chip (-1 = heuristic)
+// problems too small for the 256-wide tiles (ViT-L/14 on 4 images = 1028 rows, projector): these are latency-bound, so
+// the tile is chosen by how many workgroups it yields (tools/gemm_bench.py --small: 64x128 wins up to ~96 tiles of
+// 128x128, the 128x128 LDS-DMA kernel up to ~320, beyond that the register-staged 128x128 kernel at 2 workgroups/CU)
+static int small_variant(int M, int N, int K) {
+  (void)K;
+  if (g_opt_small >= 0) return g_opt_small;
+  const int64_t t = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+  return t <= 96 ? 4 : (t <= 320 ? 3 : 0);
+}
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
 
 extern "C" int mm_attn_set_issue_waves(int v);
@@ -689,9 +710,10 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!name) return MM_ERR_ARG;
   if (!strcmp(name, "attn_issue_waves")) return mm_attn_set_issue_waves(value);
   if (!strncmp(name, "attn_", 5)) return mm_attn_option(name, value);
+  if (!strcmp(name, "gemm_small")) { if (value < -1 || value > 5) return MM_ERR_ARG; g_opt_small = value; return MM_OK; }
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
-  if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 3) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
+  if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 6) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
   return MM_ERR_ARG;
 }
 
@@ -718,44 +740,45 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
     const bool fits32 = (layout == MM_GEMM_NT) || ((int64_t)K * ldb * 2 < 0xFFFFFFFFll && (layout != MM_GEMM_TN || (int64_t)K * lda * 2 < 0xFFFFFFFFll));
     const int64_t tiles_128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
     const int64_t tiles_256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
-    int variant = 0;   // 0 = v1, 1 = 256x128x3, 2 = 256x256x2
+    int variant = 0;   // 0 = v1 (128x128 register staged); DMA tiles: 1 = 256x128, 2 = 256x256, 3 = 128x128, 4 = 64x128, 5 = 64x64
     if (fits32) {
-      if (forced == 2) variant = 1;
-      else if (forced == 3) variant = 2;
+      if (forced >= 2 && forced <= 6) variant = forced - 1;
       else if (forced == 0 && tiles_128 >= 192) variant = MM_DEFAULT_DMA_VARIANT(tiles_256);
+      else if (forced == 0) variant = small_variant(M, N, K);
     }
     if (variant) {
-      const int bn = variant == 1 ? 128 : 256;
-      g.nbm = (M + 255) / 256;
+      static const int TBM[6] = {0, 256, 256, 128, 64, 64}, TBN[6] = {0, 128, 256, 128, 128, 64};
+      const int bm = TBM[variant], bn = TBN[variant];
+      g.nbm = (M + bm - 1) / bm;
       g.nbn = (N + bn - 1) / bn;
       const int64_t nwg = (int64_t)g.nbm * g.nbn;
       if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
-      const size_t lds = 2 * (256 + bn) * G_BK * 2;
+      const size_t lds = 2 * (bm + bn) * G_BK * 2;
       static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
-      // persistent: one resident workgroup per CU (96 / 128 KiB of LDS each) walks the tiles; otherwise one tile each
+      // persistent: one resident workgroup per CU walks the tiles; otherwise one tile each
       const int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
       dim3 grid((unsigned)nblk), block(512);
+#define MM_LAUNCH_ONE(...)                                                                                               \
+  do {                                                                                                                   \
+    auto kfn = gemm_bf16_dma_kernel<__VA_ARGS__>;                                                                        \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                     \
+  } while (0)
 #define MM_LAUNCH_DMA(AKC, BKC)                                                                                          \
   do {                                                                                                                   \
-    if (variant == 1) {                                                                                                  \
-      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 128, 4, 2, 8>;                                                       \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-      hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
-    } else if (g_opt_issue_waves == 4) {                                                                                 \
-      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 256, 2, 2, 4>;                                                       \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-      hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
-    } else {                                                                                                             \
-      auto kfn = gemm_bf16_dma_kernel<AKC, BKC, 256, 256, 2, 2, 8>;                                                       \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-      hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                   \
-    }                                                                                                                    \
+    if (variant == 1) MM_LAUNCH_ONE(AKC, BKC, 256, 128, 4, 2, 8);                                                        \
+    else if (variant == 3) MM_LAUNCH_ONE(AKC, BKC, 128, 128, 2, 2, 4);                                                   \
+    else if (variant == 4) MM_LAUNCH_ONE(AKC, BKC, 64, 128, 2, 2, 4);                                                    \
+    else if (variant == 5) MM_LAUNCH_ONE(AKC, BKC, 64, 64, 2, 2, 4);                                                     \
+    else if (g_opt_issue_waves == 4) MM_LAUNCH_ONE(AKC, BKC, 256, 256, 2, 2, 4);                                         \
+    else MM_LAUNCH_ONE(AKC, BKC, 256, 256, 2, 2, 8);                                                                     \
   } while (0)
       switch (layout) {
         case MM_GEMM_NT: MM_LAUNCH_DMA(true, true); break;
         case MM_GEMM_NN: MM_LAUNCH_DMA(true, false); break;
         default: MM_LAUNCH_DMA(false, false); break;
       }
+#undef MM_LAUNCH_ONE
 #undef MM_LAUNCH_DMA
     } else {
       g.nbm = (M + BM - 1) / BM;
@@ -791,7 +814,7 @@ extern "C" int mm_colsum(int dtype, const void* X, int M, int N, int ldx, void* 
   hipStream_t s = (hipStream_t)stream;
   const int vn = dtype == MM_BF16 ? 8 : 4;
   if ((ldx % vn) || !mm_aligned16(X)) return MM_ERR_ALIGN;
-  dim3 grid((N + 32 * vn - 1) / (32 * vn)), block(256);
+  dim3 grid((N + 8 * vn - 1) / (8 * vn)), block(256);
   if (dtype == MM_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, s, (const bf16*)X, M, N, ldx, (bf16*)out, accumulate);
   else

@@ -136,7 +136,7 @@ DMA_SHAPES = [(256, 256, 64), (300, 520, 192), (1028, 1024, 640), (129, 72, 1088
               (64, 130, 72)]
 
 
-@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
 @pytest.mark.parametrize("shape", DMA_SHAPES)
 def test_gemm_dma_kernels_forced(K, variant, layout, shape):

@@ -66,6 +66,36 @@ def main():
                 print(f"{lay} M={M:6d} N={N:6d} K={Kd:6d}  {name}={v0}: {fl / med[v0] / 1e9:7.1f} TF/s   {name}={v1}: {fl / med[v1] / 1e9:7.1f} TF/s", flush=True)
         print("TOTAL ms", tot)
         return
+    if "--small" in sys.argv:             # ViT-L/14 (4 images = 1028 tokens) and projector shapes: every kernel variant, same process
+        T2 = 1028
+        shapes = {"NT": [(T2, 3072, 1024), (T2, 1024, 1024), (T2, 4096, 1024), (T2, 1024, 4096), (1024, 4096, 4096)],
+                  "NN": [(T2, 1024, 3072), (T2, 1024, 1024), (T2, 1024, 4096), (T2, 4096, 1024), (1024, 4096, 4096)],
+                  "TN": [(3072, 1024, T2), (1024, 1024, T2), (4096, 1024, T2), (1024, 4096, T2), (4096, 4096, 1024)]}
+        names = {1: "v1", 2: "256x128", 4: "128x128", 5: "64x128", 6: "64x64"}
+        tot = {m: 0.0 for m in names}
+        for lay, shp in shapes.items():
+            for (M, N, Kd) in shp:
+                a, b = operands(lay, M, N, Kd)
+                c = torch.empty(M, pad64(N), device="cuda", dtype=torch.bfloat16)[:, :N]
+                res = {m: [] for m in names}
+                for rnd in range(5):
+                    for mode in names:
+                        set_opt("gemm_kernel", mode)
+                        K.gemm(LAY[lay], a, b, M, N, Kd, out=c)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(5):
+                            K.gemm(LAY[lay], a, b, M, N, Kd, out=c)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        res[mode].append(e0.elapsed_time(e1) / 5)
+                med = {m: sorted(v)[len(v) // 2] for m, v in res.items()}
+                for m in med:
+                    tot[m] += med[m]
+                print(f"{lay} M={M:5d} N={N:5d} K={Kd:5d}  " + "  ".join(f"{names[m]} {med[m] * 1e3:6.1f}us" for m in names), flush=True)
+        set_opt("gemm_kernel", 0)
+        print("TOTAL us", {names[m]: round(v * 1e3, 1) for m, v in tot.items()})
+        return
     if "--ab-persist" in sys.argv:        # same process, same device: interleaved A/B of the persistent tile loop
         for lay, shapes in SHAPES.items():
             for (M, N, Kd) in shapes:
