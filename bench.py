@@ -25,6 +25,8 @@ WORKLOADS = {
     "llama31_8b_vitl14_s2048_b4": ("meta-llama/Llama-3.1-8B-Instruct", "openai/clip-vit-large-patch14", 4, 2048, 1),
     "llama32_1b_vitb32_s2048_b4": ("meta-llama/Llama-3.2-1B-Instruct", "openai/clip-vit-base-patch32", 4, 2048, 1),
     "llama31_8b_vitl14_s4096_b2_4img": ("meta-llama/Llama-3.1-8B-Instruct", "openai/clip-vit-large-patch14", 2, 4096, 4),
+    # BASELINE config 5: alternate embedder / LLM through the modality plug-in (meditron_siglip) and the Qwen2 preset
+    "qwen2_7b_siglip_so400m_s2048_b4": ("Qwen/Qwen2-7B-Instruct", "google/siglip-so400m-patch14-384", 4, 2048, 1),
 }
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak of gfx950 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
@@ -40,7 +42,7 @@ def flops_per_sample(llm, vis, S, n_img, vocab, hidden_proj):
     f = 2.0 * lin * S + 0.5 * 4.0 * S * S * qo * L
     Dv, Iv, Lv = vis["hidden_size"], vis["intermediate_size"], vis["num_hidden_layers"]
     P = (vis["image_size"] // vis["patch_size"]) ** 2
-    T = P + 1
+    T = P + (0 if vis.get("kind") == "siglip" else 1)       # SigLIP has no CLS token
     vlin = Lv * (4 * Dv * Dv + 2 * Dv * Iv)
     fv = 2.0 * vlin * T + 4.0 * T * T * Dv * Lv + 2.0 * P * 3 * vis["patch_size"] ** 2 * Dv
     fp = 2.0 * P * (Dv * Dv + Dv * hidden_proj + hidden_proj * hidden_proj)
@@ -186,7 +188,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from multimeditron_amd.model.model import MultimodalConfig, MultiModalModelForCausalLM
-    from multimeditron_amd.model.modalities import ImageConfig
+    from multimeditron_amd.model.modalities import ImageConfig, SiglipImageConfig
     from multimeditron_amd.model.presets import resolve_llm_config, resolve_vision_config
     from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
 
@@ -194,7 +196,8 @@ def main():
     llm, vis = resolve_llm_config(llm_name), resolve_vision_config(clip_name)
     vocab = llm["vocab_size"] + 2          # + <|image_start|>, <|image_end|> (reference cli/train.py:99-104)
     torch.manual_seed(1234)
-    cfg = MultimodalConfig(vocab_size=vocab, modalities=[ImageConfig(hidden_size=llm["hidden_size"], clip_name=clip_name)],
+    mod_cls = SiglipImageConfig if vis.get("kind") == "siglip" else ImageConfig
+    cfg = MultimodalConfig(vocab_size=vocab, modalities=[mod_cls(hidden_size=llm["hidden_size"], clip_name=clip_name)],
                            llm_path=llm_name, dtype="bfloat16", eos_token_idx=128009, hidden_size=llm["hidden_size"])
     model = MultiModalModelForCausalLM(cfg, device=dev)
     model.pack_parameters()

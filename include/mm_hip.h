@@ -39,7 +39,8 @@ enum {
   MM_EPI_GELU_ERF = 2,   /* exact GELU (projectors/mlp.py:35,37)           */
   MM_EPI_QUICK_GELU = 4, /* x*sigmoid(1.702x) (HF:activations.py:117-123)  */
   MM_EPI_RESIDUAL = 8,   /* + residual[M,N] (ldr)                          */
-  MM_EPI_ACCUMULATE = 16 /* C += result (gradient accumulation)            */
+  MM_EPI_ACCUMULATE = 16,/* C += result (gradient accumulation)            */
+  MM_EPI_GELU_TANH = 32  /* tanh GELU (HF:activations.py gelu_pytorch_tanh; SigLIP MLP) */
 };
 
 int mm_version(void);
@@ -82,6 +83,13 @@ int mm_vit_embed_fwd(int dtype, const void* patch_out, const void* cls, const vo
 int mm_vit_embed_bwd(int dtype, const void* dx, int n, int P, int D, void* dpatch_out, void* dcls, void* dpos,
                      int accumulate, void* stream);
 /* dst[n,P,D] = src[n,1+P,D][:,1:,:] (image_modality.py:133) and its adjoint (zero CLS row)                */
+/* ---- plug-in towers without a CLS token and with head_dim outside {64,128} (SigLIP-so400m: 16 heads x 72) ----------
+ * mm_bcast_add: y[n,L] = x[n,L] + b[L]  (learned positions added to every image; HF:siglip SiglipVisionEmbeddings)
+ * mm_head_pad:  inverse = 0: dst[rows, nheads*dpad] = src[rows, nheads*d] with each head zero-padded to dpad;
+ *               inverse = 1: dst[rows, nheads*d] = the first d columns of every head of src[rows, nheads*dpad].
+ *               Zero columns change neither q.k nor p.v, so attention on the padded heads is exact.                  */
+int mm_bcast_add(int dtype, const void* x, const void* b, int n, int64_t L, void* y, void* stream);
+int mm_head_pad(int dtype, const void* src, int64_t rows, int nheads, int d, int dpad, void* dst, int inverse, void* stream);
 int mm_drop_cls_fwd(int dtype, const void* src, int n, int P, int D, void* dst, void* stream);
 int mm_drop_cls_bwd(int dtype, const void* ddst, int n, int P, int D, void* dsrc, void* stream);
 
@@ -132,6 +140,7 @@ int mm_attn_bwd(int dtype, const void* q, const void* k, const void* v, const vo
 int mm_swiglu_fwd(int dtype, const void* gu, int M, int I, void* out, void* stream);
 int mm_swiglu_bwd(int dtype, const void* gu, const void* dout, int M, int I, void* dgu, void* stream);
 /* kind: 0 = erf GELU (mlp.py:35,37), 1 = quick GELU (HF:clip fc1).  x is the pre-activation.                       */
+/* kind: 0 = erf GELU, 1 = quick GELU, 2 = tanh GELU */
 int mm_gelu_fwd(int dtype, int kind, const void* x, int64_t n, void* y, void* stream);
 int mm_gelu_bwd(int dtype, int kind, const void* x, const void* dy, int64_t n, void* dx, void* stream);
 /* y = a + b (residual adds that are not fused into a GEMM epilogue)                                             */

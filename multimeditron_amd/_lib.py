@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("MM_HIP_LIBRARY") or os.path.join(_PKG, "libmmhip.so")
 
 MM_BF16, MM_F32 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS, EPI_GELU_ERF, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_ACCUMULATE = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_GELU_ERF, EPI_QUICK_GELU, EPI_RESIDUAL, EPI_ACCUMULATE, EPI_GELU_TANH = 1, 2, 4, 8, 16, 32
+GELU_KIND = {EPI_GELU_ERF: 0, EPI_QUICK_GELU: 1, EPI_GELU_TANH: 2}      # mm_gelu_fwd/bwd `kind` of each epilogue flag
 
 
 class MMHipError(RuntimeError):

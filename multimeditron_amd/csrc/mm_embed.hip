@@ -226,7 +226,7 @@ extern "C" int mm_embed_splice_bwd(int dtype, const void* dE, int H, const int64
 }
 
 extern "C" int mm_patchify(int dtype, const float* pixels, int n, int himg, int wimg, int ps, int kpad, void* patches, void* stream) {
-  if (!pixels || !patches || n < 0 || ps <= 0 || himg % ps || wimg % ps || kpad < 3 * ps * ps) return MM_ERR_ARG;
+  if (!pixels || !patches || n < 0 || ps <= 0 || himg < ps || wimg < ps || kpad < 3 * ps * ps) return MM_ERR_ARG;   // a ragged border is dropped, as a stride-ps "valid" conv does (SigLIP 384 / 14)
   if (n == 0) return MM_OK;
   const int64_t total = (int64_t)n * (himg / ps) * (wimg / ps) * kpad;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -285,4 +285,73 @@ extern "C" int mm_drop_cls_fwd(int dtype, const void* src, int n, int P, int D, 
 }
 extern "C" int mm_drop_cls_bwd(int dtype, const void* ddst, int n, int P, int D, void* dsrc, void* stream) {
   return drop_cls_launch<true>(dtype, ddst, n, P, D, dsrc, stream);
+}
+
+// ---- plug-in towers: learned positions without a CLS row, heads padded to a width the MFMA attention supports ----------
+namespace {
+template <typename T>
+__global__ void bcast_add_kernel(const T* x, const T* b, int64_t L, int64_t total, T* y) {
+  constexpr int VN = Vec16<T>::N;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VN;
+  if (i >= total) return;
+  const int64_t j = i % L;                 // L % VN == 0: a vector never straddles two images
+  Vec16<T> xv = *(const Vec16<T>*)(x + i), bv = *(const Vec16<T>*)(b + j), o;
+#pragma unroll
+  for (int k = 0; k < VN; ++k) o.set(k, xv.get(k) + bv.get(k));
+  *(Vec16<T>*)(y + i) = o;
+}
+
+// one thread = one 16-byte vector of the WIDE side [rows, nheads, dpad]
+template <typename T, bool INVERSE>
+__global__ void head_pad_kernel(const T* src, int64_t rows, int nheads, int d, int dpad, T* dst) {
+  constexpr int VN = Vec16<T>::N;
+  const int vpw = dpad / VN;                                   // vectors per padded head
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nheads * vpw) return;
+  const int c = (int)(i % vpw) * VN;
+  const int64_t rh = i / vpw;                                  // row * nheads + head
+  if (INVERSE) {
+    if (c < d) *(Vec16<T>*)(dst + rh * d + c) = *(const Vec16<T>*)(src + rh * dpad + c);
+  } else {
+    Vec16<T> v;
+#pragma unroll
+    for (int k = 0; k < VN; ++k) v.set(k, 0.f);
+    if (c < d) v = *(const Vec16<T>*)(src + rh * d + c);
+    *(Vec16<T>*)(dst + rh * dpad + c) = v;
+  }
+}
+}  // namespace
+
+extern "C" int mm_bcast_add(int dtype, const void* x, const void* b, int n, int64_t L, void* y, void* stream) {
+  if (!x || !b || !y || n < 0 || L <= 0) return MM_ERR_ARG;
+  if (dtype != MM_BF16 && dtype != MM_F32) return MM_ERR_UNSUPPORTED;
+  if (n == 0) return MM_OK;
+  const int vn = dtype == MM_BF16 ? 8 : 4;
+  if (L % vn || !mm_aligned16(x) || !mm_aligned16(b) || !mm_aligned16(y)) return MM_ERR_ALIGN;
+  const int64_t total = (int64_t)n * L;
+  dim3 grid((unsigned)((total / vn + 255) / 256)), block(256);
+  if (dtype == MM_BF16)
+    hipLaunchKernelGGL(bcast_add_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)b, L, total, (bf16*)y);
+  else
+    hipLaunchKernelGGL(bcast_add_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, (const float*)b, L, total, (float*)y);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_head_pad(int dtype, const void* src, int64_t rows, int nheads, int d, int dpad, void* dst, int inverse,
+                           void* stream) {
+  if (!src || !dst || rows < 0 || nheads <= 0 || d <= 0 || dpad < d) return MM_ERR_ARG;
+  if (dtype != MM_BF16 && dtype != MM_F32) return MM_ERR_UNSUPPORTED;
+  if (rows == 0) return MM_OK;
+  const int vn = dtype == MM_BF16 ? 8 : 4;
+  if (d % vn || dpad % vn || !mm_aligned16(src) || !mm_aligned16(dst)) return MM_ERR_ALIGN;
+  const int64_t total = rows * nheads * (dpad / vn);
+  if ((total + 255) / 256 > 0x7FFFFFFF) return MM_ERR_ARG;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define MM_HP(T, INV) hipLaunchKernelGGL((head_pad_kernel<T, INV>), grid, block, 0, (hipStream_t)stream, (const T*)src, rows, nheads, d, dpad, (T*)dst)
+  if (dtype == MM_BF16) { if (inverse) MM_HP(bf16, true); else MM_HP(bf16, false); }
+  else { if (inverse) MM_HP(float, true); else MM_HP(float, false); }
+#undef MM_HP
+  MM_CHECK_LAUNCH();
+  return MM_OK;
 }

@@ -40,6 +40,10 @@ struct GemmArgs {
 
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float act_gelu_tanh(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);   // tanh(u) = 1 - 2/(1+exp(2u))
+  return 0.5f * x * (2.0f - 2.0f / (1.0f + __expf(2.0f * u)));
+}
 
 __device__ __forceinline__ void block_to_tile(int bid, int nbm, int nbn, int& pm, int& pn) {
   const int nwg = nbm * nbn;
@@ -172,6 +176,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
       } else if (epi & MM_EPI_QUICK_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = act_quick_gelu(v[r]);
+      } else if (epi & MM_EPI_GELU_TANH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_gelu_tanh(v[r]);
       }
       if (epi & MM_EPI_RESIDUAL) {
         const bf16* rp = R + (int64_t)m * g.ldr + n;
@@ -630,6 +637,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (g.epi & MM_EPI_BIAS) v += bias[n];
         if (g.epi & MM_EPI_GELU_ERF) v = act_gelu_erf(v);
         else if (g.epi & MM_EPI_QUICK_GELU) v = act_quick_gelu(v);
+        else if (g.epi & MM_EPI_GELU_TANH) v = act_gelu_tanh(v);
         if (g.epi & MM_EPI_RESIDUAL) v += R[(int64_t)m * g.ldr + n];
         float* cp = C + (int64_t)m * g.ldc + n;
         if (g.epi & MM_EPI_ACCUMULATE) v += *cp;

@@ -330,10 +330,19 @@ __global__ void gelu_kernel(const T* x, const T* dy, int64_t n, T* y) {
   if (i >= n) return;
   auto f = [](float v) -> float {
     if (KIND == 0) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (KIND == 2) {
+      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      return 0.5f * v * (2.0f - 2.0f / (1.0f + __expf(2.0f * u)));
+    }
     return v / (1.0f + __expf(-1.702f * v));
   };
   auto df = [](float v) -> float {
     if (KIND == 0) return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * __expf(-0.5f * v * v);
+    if (KIND == 2) {   // d/dv [0.5 v (1 + tanh u)], u = c (v + 0.044715 v^3)
+      const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      const float th = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
+      return 0.5f * (1.0f + th) + 0.5f * v * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * v * v);
+    }
     const float s = 1.0f / (1.0f + __expf(-1.702f * v));
     return s * (1.0f + 1.702f * v * (1.0f - s));
   };
@@ -648,20 +657,22 @@ static int gelu_launch(int kind, const void* x, const void* dy, int64_t n, void*
   dim3 grid((unsigned)((n / VN + 256) / 256)), block(256);
   if (kind == 0)
     hipLaunchKernelGGL((gelu_kernel<T, 0, BWD>), grid, block, 0, s, (const T*)x, (const T*)dy, n, (T*)y);
-  else
+  else if (kind == 1)
     hipLaunchKernelGGL((gelu_kernel<T, 1, BWD>), grid, block, 0, s, (const T*)x, (const T*)dy, n, (T*)y);
+  else
+    hipLaunchKernelGGL((gelu_kernel<T, 2, BWD>), grid, block, 0, s, (const T*)x, (const T*)dy, n, (T*)y);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
 
 extern "C" int mm_gelu_fwd(int dtype, int kind, const void* x, int64_t n, void* y, void* stream) {
-  if (!x || !y || n < 0 || kind < 0 || kind > 1) return MM_ERR_ARG;
+  if (!x || !y || n < 0 || kind < 0 || kind > 2) return MM_ERR_ARG;
   if (n == 0) return MM_OK;
   return dtype == MM_BF16 ? gelu_launch<bf16, false>(kind, x, nullptr, n, y, (hipStream_t)stream)
                           : gelu_launch<float, false>(kind, x, nullptr, n, y, (hipStream_t)stream);
 }
 extern "C" int mm_gelu_bwd(int dtype, int kind, const void* x, const void* dy, int64_t n, void* dx, void* stream) {
-  if (!x || !dy || !dx || n < 0 || kind < 0 || kind > 1) return MM_ERR_ARG;
+  if (!x || !dy || !dx || n < 0 || kind < 0 || kind > 2) return MM_ERR_ARG;
   if (n == 0) return MM_OK;
   return dtype == MM_BF16 ? gelu_launch<bf16, true>(kind, x, dy, n, dx, (hipStream_t)stream)
                           : gelu_launch<float, true>(kind, x, dy, n, dx, (hipStream_t)stream);

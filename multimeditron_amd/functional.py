@@ -12,7 +12,7 @@ from typing import Callable, Optional
 import torch
 
 from . import kernels as K
-from ._lib import EPI_GELU_ERF, EPI_QUICK_GELU
+from ._lib import EPI_GELU_ERF, EPI_QUICK_GELU, GELU_KIND  # noqa: F401
 
 # called as hook(param) right after a parameter's gradient for this step is complete (DP bucket scheduling)
 _grad_ready_hook: Optional[Callable] = None
@@ -108,7 +108,7 @@ class LinearFn(torch.autograd.Function):
         pre = None
         if act and (x.requires_grad or wg.requires_grad):
             pre = K.linear_fwd(x, w, bias=b)                      # keep the pre-activation for backward
-            y = K.gelu_fwd(pre, 0 if act == EPI_GELU_ERF else 1)
+            y = K.gelu_fwd(pre, GELU_KIND[act])
             if residual is not None:
                 y = K.add(y, residual)
         else:
@@ -126,7 +126,7 @@ class LinearFn(torch.autograd.Function):
             dy = dy.contiguous()
         dres = dy if ctx.has_res else None
         if ctx.act:
-            dy = K.gelu_bwd(pre, dy, 0 if ctx.act == EPI_GELU_ERF else 1)
+            dy = K.gelu_bwd(pre, dy, GELU_KIND[ctx.act])
         if bg is not None and bg.requires_grad:
             g, acc = bg.grad_target()
             K.colsum(dy, g, acc)
@@ -245,6 +245,39 @@ def rope_attention(qkv, cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale):
     return RopeAttentionFn.apply(qkv, cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale)
 
 
+class HeadPadFn(torch.autograd.Function):
+    """[rows, nheads*d] <-> [rows, nheads*dpad]: zero-pad (or strip) every head so that a head width the MFMA attention
+    does not tile (SigLIP-so400m: 72) runs on the D = 64 / 128 kernels.  Zero columns add nothing to q.k and give zero
+    columns of p.v, so the result is exact; the backward of a pad is a strip and vice versa."""
+
+    @staticmethod
+    def forward(ctx, x, nheads, d, dpad, inverse):
+        ctx.meta = (nheads, d, dpad, inverse)
+        return K.head_pad(x.contiguous(), nheads, d, dpad, inverse)
+
+    @staticmethod
+    def backward(ctx, dy):
+        nheads, d, dpad, inverse = ctx.meta
+        return K.head_pad(dy.contiguous(), nheads, d, dpad, not inverse), None, None, None, None
+
+
+def head_pad(x, nheads, d, dpad):
+    return HeadPadFn.apply(x, nheads, d, dpad, False)
+
+
+def head_strip(x, nheads, d, dpad):
+    return HeadPadFn.apply(x, nheads, d, dpad, True)
+
+
+def attention_head_width(d: int, dtype) -> int:
+    """Head width the attention kernels run a head of width d at (bf16 MFMA path: 64 or 128; fp32 path: any)."""
+    if dtype == torch.float32 or d in (64, 128):
+        return d
+    if d > 128:
+        raise ValueError(f"head_dim {d} > 128 is not supported by the bf16 attention kernels")
+    return 64 if d < 64 else 128
+
+
 # --------------------------------------------------------------------------------------------------- activations
 class SwiGLUFn(torch.autograd.Function):
     @staticmethod
@@ -325,10 +358,11 @@ def embed_splice(emb, ids, proj, batch_idx, token_range, B, S, dummy=None):
 
 # --------------------------------------------------------------------------------------------------- ViT glue
 class PatchEmbedFn(torch.autograd.Function):
-    """HF:clip:138-218: conv(k=s=patch) as patchify + GEMM, + CLS + position embedding."""
+    """conv(k=s=patch) as patchify + GEMM, then positions.  CLIP (HF:clip:138-218): no conv bias, CLS row prepended.
+    SigLIP (HF:siglip SiglipVisionEmbeddings): conv bias, no CLS row (cls is None)."""
 
     @staticmethod
-    def forward(ctx, pixels, dummy, w_conv, cls, pos, ps):
+    def forward(ctx, pixels, dummy, w_conv, b_conv, cls, pos, ps):
         n = pixels.shape[0]
         Dv = w_conv.shape[0]
         kk = 3 * ps * ps
@@ -337,33 +371,48 @@ class PatchEmbedFn(torch.autograd.Function):
         patches = K.patchify(pixels.contiguous(), ps, kpad, dtype)
         wp = torch.zeros((Dv, kpad), dtype=dtype, device=w_conv.device)
         wp[:, :kk].copy_(w_conv.data.reshape(Dv, kk))
-        po = K.linear_fwd(patches, wp)
+        po = K.linear_fwd(patches, wp, bias=b_conv.data if b_conv is not None else None)
         P = patches.shape[0] // n
-        x = K.vit_embed_fwd(po, cls.data, pos.data, n, P)
-        ctx.params = (w_conv, cls, pos)
+        if cls is not None:
+            x = K.vit_embed_fwd(po, cls.data, pos.data, n, P)
+            T = P + 1
+        else:
+            x = K.bcast_add(po.view(n, P * Dv), pos.data.reshape(-1))
+            T = P
+        ctx.params = (w_conv, b_conv, cls, pos)
         ctx.meta = (n, P, Dv, kk, kpad)
         ctx.save_for_backward(patches)
-        return x.view(n * (P + 1), Dv)
+        return x.view(n * T, Dv)
 
     @staticmethod
     def backward(ctx, dx):
         (patches,) = ctx.saved_tensors
-        w_conv, cls, pos = ctx.params
+        w_conv, b_conv, cls, pos = ctx.params
         n, P, Dv, kk, kpad = ctx.meta
         need_w = w_conv.requires_grad
+        need_b = b_conv is not None and b_conv.requires_grad
         gc = gp = None
         accc = accp = False
-        if cls.requires_grad:
+        if cls is not None and cls.requires_grad:
             gc, accc = grad_target(cls)
         if pos.requires_grad:
             gp, accp = grad_target(pos)
-        if not (need_w or gc is not None or gp is not None):
-            return (None,) * 6
-        dx = dx.contiguous().view(n, P + 1, Dv)
-        if gc is not None and gp is not None and accc != accp:   # kernel takes one flag: normalise by zeroing
-            (gc if not accc else gp).zero_()
-            accc = accp = True
-        dpatch = K.vit_embed_bwd(dx, gc, gp, accc or accp, want_dpatch=need_w)
+        if not (need_w or need_b or gc is not None or gp is not None):
+            return (None,) * 7
+        if cls is not None:
+            dx = dx.contiguous().view(n, P + 1, Dv)
+            if gc is not None and gp is not None and accc != accp:   # kernel takes one flag: normalise by zeroing
+                (gc if not accc else gp).zero_()
+                accc = accp = True
+            dpatch = K.vit_embed_bwd(dx, gc, gp, accc or accp, want_dpatch=need_w or need_b)
+        else:
+            dpatch = dx.contiguous().view(n * P, Dv)                 # no CLS row: the patch gradient IS dx
+            if gp is not None:
+                K.colsum(dpatch.view(n, P * Dv), gp.view(-1), accp)
+        if need_b:
+            g, acc = grad_target(b_conv)
+            K.colsum(dpatch, g, acc)
+            _ready(b_conv)
         if need_w:
             gw = torch.empty((Dv, kpad), dtype=dx.dtype, device=dx.device)
             K.linear_wgrad(dpatch, patches, gw, False)
@@ -374,13 +423,13 @@ class PatchEmbedFn(torch.autograd.Function):
                 g.copy_(gw[:, :kk].reshape(g.shape))
             _ready(w_conv)
         for p in (cls, pos):
-            if p.requires_grad:
+            if p is not None and p.requires_grad:
                 _ready(p)
-        return (None,) * 6
+        return (None,) * 7
 
 
-def patch_embed(pixels, w_conv, cls, pos, ps, dummy=None):
-    return PatchEmbedFn.apply(pixels, dummy, w_conv, cls, pos, ps)
+def patch_embed(pixels, w_conv, cls, pos, ps, dummy=None, b_conv=None):
+    return PatchEmbedFn.apply(pixels, dummy, w_conv, b_conv, cls, pos, ps)
 
 
 class DropClsFn(torch.autograd.Function):

@@ -140,6 +140,22 @@ def vit_embed_bwd(dx, dcls, dpos, accumulate, want_dpatch=True):
     return dpatch
 
 
+def bcast_add(x, b):
+    """y[n, ...] = x[n, ...] + b[...] (b broadcast over the leading axis)."""
+    y = torch.empty_like(x)
+    call("mm_bcast_add", dt(x), _p(x), _p(b), x.shape[0], b.numel(), _p(y), _stream())
+    return y
+
+
+def head_pad(x2d, nheads, d, dpad, inverse=False):
+    """[rows, nheads*d] -> [rows, nheads*dpad] (zero-padded heads), or back with inverse=True."""
+    rows = x2d.shape[0]
+    assert x2d.is_contiguous() and x2d.shape[1] == nheads * (dpad if inverse else d)
+    out = torch.empty((rows, nheads * (d if inverse else dpad)), dtype=x2d.dtype, device=x2d.device)
+    call("mm_head_pad", dt(x2d), _p(x2d), rows, nheads, d, dpad, _p(out), int(inverse), _stream())
+    return out
+
+
 def drop_cls_fwd(x):
     n, T, D = x.shape
     out = torch.empty((n, T - 1, D), dtype=x.dtype, device=x.device)

@@ -1,5 +1,6 @@
 from .base import AutoModality, BaseModality, BaseModalityConfig, BaseModalityProcessor
 from .image_modality import ImageConfig, ImageModality, ImageProcessor
+from .siglip_modality import SiglipImageConfig, SiglipImageModality, SiglipImageProcessor
 
 __all__ = ["BaseModality", "BaseModalityConfig", "BaseModalityProcessor", "AutoModality", "ImageConfig", "ImageModality",
-           "ImageProcessor"]
+           "ImageProcessor", "SiglipImageConfig", "SiglipImageModality", "SiglipImageProcessor"]

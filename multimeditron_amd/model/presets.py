@@ -32,6 +32,10 @@ VISION_PRESETS: Dict[str, Dict[str, Any]] = {
                                          image_size=224, patch_size=32, hidden_act="quick_gelu", layer_norm_eps=1e-5),
 }
 
+VISION_PRESETS["google/siglip-so400m-patch14-384"] = dict(
+    kind="siglip", hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16, image_size=384,
+    patch_size=14, hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6)
+
 CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
 CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
 
@@ -53,7 +57,11 @@ def resolve_llm_config(llm_path: str) -> Dict[str, Any]:
 def resolve_vision_config(clip_name: str) -> Dict[str, Any]:
     if os.path.isdir(clip_name):
         cfg = _read_json(os.path.join(clip_name, "config.json"))
-        return cfg.get("vision_config", cfg)
+        top_type = cfg.get("model_type", "")
+        cfg = dict(cfg.get("vision_config", cfg))
+        if "siglip" in str(cfg.get("model_type", top_type)):
+            cfg["kind"] = "siglip"
+        return cfg
     if clip_name in VISION_PRESETS:
         return dict(VISION_PRESETS[clip_name])
     raise ValueError(f"Unknown clip_name {clip_name!r}: give a local directory with config.json or one of {sorted(VISION_PRESETS)}")
@@ -63,6 +71,9 @@ def resolve_preprocessor_config(clip_name: str, image_size: int) -> Dict[str, An
     base = dict(do_resize=True, size={"shortest_edge": image_size}, resample=3, do_center_crop=True,
                 crop_size={"height": image_size, "width": image_size}, do_rescale=True, rescale_factor=1 / 255,
                 do_normalize=True, image_mean=CLIP_MEAN, image_std=CLIP_STD, do_convert_rgb=True)
+    if resolve_vision_config(clip_name).get("kind") == "siglip":      # HF SiglipImageProcessor defaults: plain resize, mean = std = 0.5
+        base.update(size={"height": image_size, "width": image_size}, do_center_crop=False,
+                    image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5])
     p = os.path.join(clip_name, "preprocessor_config.json") if os.path.isdir(clip_name) else None
     if p and os.path.exists(p):
         base.update({k: v for k, v in _read_json(p).items() if v is not None})

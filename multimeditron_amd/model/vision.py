@@ -13,7 +13,9 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fm
-from .._lib import EPI_GELU_ERF, EPI_QUICK_GELU
+from .._lib import EPI_GELU_ERF, EPI_GELU_TANH, EPI_QUICK_GELU
+
+_ACT = {"quick_gelu": EPI_QUICK_GELU, "gelu": EPI_GELU_ERF, "gelu_pytorch_tanh": EPI_GELU_TANH}
 from ..nn import Linear, Norm, grad_dummy
 
 
@@ -28,6 +30,8 @@ class VisionConfig:
     hidden_act: str = "quick_gelu"
     layer_norm_eps: float = 1e-5
     num_channels: int = 3
+    kind: str = "clip"          # "clip": CLS token, bias-free conv, pre_layrnorm, tokens returned before post-LN
+                                # "siglip": no CLS, conv bias, no pre-LN, post_layernorm on the returned tokens
 
     @classmethod
     def from_dict(cls, d: Dict[str, Any]):
@@ -46,6 +50,10 @@ class _PatchConv(nn.Module):
     def __init__(self, cfg, dtype, device):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(cfg.hidden_size, cfg.num_channels, cfg.patch_size, cfg.patch_size, dtype=dtype, device=device))
+        if cfg.kind == "siglip":
+            self.bias = nn.Parameter(torch.empty(cfg.hidden_size, dtype=dtype, device=device))
+        else:
+            self.bias = None
 
 
 class _PosEmb(nn.Module):
@@ -58,9 +66,10 @@ class VisionEmbeddings(nn.Module):
     def __init__(self, cfg: VisionConfig, dtype, device):
         super().__init__()
         self.cfg = cfg
-        self.class_embedding = nn.Parameter(torch.empty(cfg.hidden_size, dtype=dtype, device=device))
+        has_cls = cfg.kind != "siglip"
+        self.class_embedding = nn.Parameter(torch.empty(cfg.hidden_size, dtype=dtype, device=device)) if has_cls else None
         self.patch_embedding = _PatchConv(cfg, dtype, device)
-        self.position_embedding = _PosEmb(cfg.num_patches + 1, cfg.hidden_size, dtype, device)
+        self.position_embedding = _PosEmb(cfg.num_patches + (1 if has_cls else 0), cfg.hidden_size, dtype, device)
 
     def forward(self, pixels):
         c = self.cfg
@@ -68,7 +77,8 @@ class VisionEmbeddings(nn.Module):
             raise ValueError(f"Input image size ({pixels.shape[-2]}*{pixels.shape[-1]}) doesn't match model "
                              f"({c.image_size}*{c.image_size}).")
         return Fm.patch_embed(pixels.float(), self.patch_embedding.weight, self.class_embedding,
-                              self.position_embedding.weight, c.patch_size, dummy=grad_dummy(self.patch_embedding.weight))
+                              self.position_embedding.weight, c.patch_size, dummy=grad_dummy(self.patch_embedding.weight),
+                              b_conv=self.patch_embedding.bias)
 
 
 class VisionAttention(nn.Module):
@@ -90,7 +100,9 @@ class VisionMLP(nn.Module):
         super().__init__()
         self.fc1 = Linear(cfg.hidden_size, cfg.intermediate_size, dtype=dtype, device=device)
         self.fc2 = Linear(cfg.intermediate_size, cfg.hidden_size, dtype=dtype, device=device)
-        self.act = EPI_QUICK_GELU if cfg.hidden_act == "quick_gelu" else EPI_GELU_ERF
+        if cfg.hidden_act not in _ACT:
+            raise ValueError(f"unsupported vision hidden_act {cfg.hidden_act!r} (have {sorted(_ACT)})")
+        self.act = _ACT[cfg.hidden_act]
 
 
 class VisionLayer(nn.Module):
@@ -105,7 +117,12 @@ class VisionLayer(nn.Module):
         a = self.self_attn
         h, x = self.layer_norm1(x)
         qkv = Fm.linear(h, a._wqkv, a._bqkv, dummy=grad_dummy(a.q_proj.weight))
-        o = Fm.rope_attention(qkv, None, None, None, n, T, a.heads, a.heads, a.hd, False, a.hd ** -0.5)
+        hw = Fm.attention_head_width(a.hd, qkv.dtype)
+        if hw != a.hd:      # e.g. SigLIP-so400m: 16 heads x 72 run as 16 x 128 with zero columns (exact)
+            qkv = Fm.head_pad(qkv, 3 * a.heads, a.hd, hw)
+        o = Fm.rope_attention(qkv, None, None, None, n, T, a.heads, a.heads, hw, False, a.hd ** -0.5)
+        if hw != a.hd:
+            o = Fm.head_strip(o, a.heads, a.hd, hw)
         x = a.out_proj(o, residual=x)
         h, x = self.layer_norm2(x)
         h = self.mlp.fc1(h, act=self.mlp.act)
@@ -128,22 +145,27 @@ class VisionTransformer(nn.Module):
         super().__init__()
         self.config = cfg
         self.embeddings = VisionEmbeddings(cfg, dtype, device)
-        self.pre_layrnorm = Norm(cfg.hidden_size, cfg.layer_norm_eps, bias=True, dtype=dtype, device=device)
+        siglip = cfg.kind == "siglip"
+        self.pre_layrnorm = None if siglip else Norm(cfg.hidden_size, cfg.layer_norm_eps, bias=True, dtype=dtype, device=device)
         self.encoder = VisionEncoder(cfg, dtype, device)
+        self.post_layernorm = Norm(cfg.hidden_size, cfg.layer_norm_eps, bias=True, dtype=dtype, device=device) if siglip else None
 
     def forward(self, pixel_values, stages=None) -> VisionOutput:
         n = pixel_values.shape[0]
-        T = self.config.num_patches + 1
+        T = self.config.num_patches + (0 if self.config.kind == "siglip" else 1)
         x = self.embeddings(pixel_values)
         if stages is not None:
             stages["vit_embeddings"] = x.view(n, T, -1)
-        x, _ = self.pre_layrnorm(x)
-        if stages is not None:
-            stages["vit_pre_ln"] = x.view(n, T, -1)
+        if self.pre_layrnorm is not None:
+            x, _ = self.pre_layrnorm(x)
+            if stages is not None:
+                stages["vit_pre_ln"] = x.view(n, T, -1)
         for i, layer in enumerate(self.encoder.layers):
             x = layer(x, n, T)
             if stages is not None and i == 0:
                 stages["vit_layer0"] = x.view(n, T, -1)
+        if self.post_layernorm is not None:
+            x, _ = self.post_layernorm(x)
         return VisionOutput(last_hidden_state=x.view(n, T, -1))
 
 
@@ -159,4 +181,19 @@ class CLIPFeatureExtractor(nn.Module):
 
     @property
     def device(self):
-        return self.vision_model.embeddings.class_embedding.device
+        return self.vision_model.embeddings.patch_embedding.weight.device
+
+
+class SiglipFeatureExtractor(VisionTransformer):
+    """Stands where a SigLIP plug-in keeps `SiglipVisionModel.from_pretrained(...)`: transformers 5.x holds
+    embeddings / encoder / post_layernorm directly on that model (no `.vision_model` level), and so do the parameter
+    names here.  The attention-pooling head of the HF model is not on the token path and is not instantiated."""
+
+    def __init__(self, cfg: VisionConfig, dtype=torch.bfloat16, device=None):
+        assert cfg.kind == "siglip"
+        super().__init__(cfg, dtype, device)
+        self.vision_embed_dim = cfg.hidden_size
+
+    @property
+    def device(self):
+        return self.embeddings.patch_embedding.weight.device

@@ -18,6 +18,10 @@ calls at that line -- `HF:` = transformers 5.15.0):
   clip_vision_tower   image_modality.py:133 -> HF:models/clip/modeling_clip.py:138-218 (embeddings),
                       :280-384 (attention/MLP/layer), :594-657 (pre_layrnorm, encoder; last_hidden_state
                       is returned WITHOUT post_layernorm)
+  siglip_vision_tower BASELINE config 5 (no reference modality: SURVEY section 0 fact 9) -> HF:models/siglip/modeling_siglip.py
+                      SiglipVisionEmbeddings (conv WITH bias + learned positions, no CLS), SiglipEncoderLayer
+                      (pre-LN, biased q/k/v/out, fc1 -> gelu_pytorch_tanh -> fc2), post_layernorm on the returned
+                      tokens; the pooling head is not on the token path
   mlp_projector       projectors/mlp.py:33-39 (Linear-GELU(erf)-Linear-GELU(erf)-Linear, all biased)
   image_modality      image_modality.py:130-137 (stack -> vision tower -> drop CLS -> projector)
   embed_splice        model.py:433-444 (embedding lookup, then index_put of projected patches)
@@ -37,6 +41,7 @@ import torch
 import torch.nn.functional as F
 
 VIS_PREFIX = "modalities_with_projection.0.feature_extractor.vision_model."
+SIGLIP_PREFIX = "modalities_with_projection.0.feature_extractor."      # transformers 5.x SiglipVisionModel layout
 PROJ_PREFIX = "modalities_with_projection.0.projector.projection."
 LLM_PREFIX = "model.model."
 
@@ -95,6 +100,30 @@ def clip_vision_tower(w: Dict[str, torch.Tensor], pixels: torch.Tensor, vis: dic
     return x
 
 
+def siglip_vision_tower(w: Dict[str, torch.Tensor], pixels: torch.Tensor, vis: dict, stages: Optional[dict] = None):
+    """pixels [n,3,H,W] -> last_hidden_state [n,P,Dv] = post_layernorm(encoder(embeddings)); no CLS token."""
+    pre = SIGLIP_PREFIX
+    pw = w[pre + "embeddings.patch_embedding.weight"]
+    x = F.conv2d(pixels.to(pw.dtype), pw, w[pre + "embeddings.patch_embedding.bias"], stride=vis["patch_size"])
+    x = x.flatten(2).transpose(1, 2) + w[pre + "embeddings.position_embedding.weight"].unsqueeze(0)
+    if stages is not None:
+        stages["vit_embeddings"] = x
+    eps = vis.get("layer_norm_eps", 1e-6)
+    for i in range(vis["num_hidden_layers"]):
+        lp = f"{pre}encoder.layers.{i}."
+        h = _layer_norm(x, w[lp + "layer_norm1.weight"], w[lp + "layer_norm1.bias"], eps)
+        x = x + _mha_noncausal(h, w, lp + "self_attn.", vis["num_attention_heads"])
+        h = _layer_norm(x, w[lp + "layer_norm2.weight"], w[lp + "layer_norm2.bias"], eps)
+        h = F.gelu(F.linear(h, w[lp + "mlp.fc1.weight"], w[lp + "mlp.fc1.bias"]), approximate="tanh")
+        x = x + F.linear(h, w[lp + "mlp.fc2.weight"], w[lp + "mlp.fc2.bias"])
+        if stages is not None and i == 0:
+            stages["vit_layer0"] = x
+    x = _layer_norm(x, w[pre + "post_layernorm.weight"], w[pre + "post_layernorm.bias"], eps)
+    if stages is not None:
+        stages["vit_last_hidden"] = x
+    return x
+
+
 def mlp_projector(w, x):
     p = PROJ_PREFIX
     x = F.gelu(F.linear(x, w[p + "0.weight"], w[p + "0.bias"]))
@@ -103,7 +132,10 @@ def mlp_projector(w, x):
 
 
 def image_modality(w, pixels, vis, stages=None):
-    feats = clip_vision_tower(w, pixels, vis, stages)[:, 1:, :]
+    if vis.get("kind") == "siglip":
+        feats = siglip_vision_tower(w, pixels, vis, stages)
+    else:
+        feats = clip_vision_tower(w, pixels, vis, stages)[:, 1:, :]
     out = mlp_projector(w, feats)
     if stages is not None:
         stages["projector_out"] = out

@@ -235,6 +235,9 @@ ATTN_CASES = [
     (1, 384, 384, 8, 2, 128, True, False),
     (2, 1, 77, 4, 2, 64, True, True),
     (1, 40, 104, 2, 1, 128, True, False),
+    (1, 300, 300, 7, 1, 128, True, False),       # Qwen2-7B's odd GQA group (28/4 = 7): one-key-block dK/dV kernel
+    (2, 640, 640, 4, 2, 128, True, True),        # 5 key blocks: odd count through the paired dK/dV kernel
+    (3, 729, 729, 2, 2, 128, False, False),      # SigLIP-so400m token count, non-causal (padded 72-wide heads run here)
 ]
 
 
@@ -365,13 +368,36 @@ def test_activations(K, dtype):
     assert rel(K.swiglu_fwd(gu.cuda(), I).float(), ref.detach()) < tol
     assert rel(K.swiglu_bwd(gu.cuda(), dout.cuda(), I).float(), guf.grad) < tol * 2
     x, dy = rnd((1000 + 3,), dtype, 43, 2.0), rnd((1000 + 3,), dtype, 44)
-    for kind, fn in [(0, F.gelu), (1, lambda t: t * torch.sigmoid(1.702 * t))]:
+    for kind, fn in [(0, F.gelu), (1, lambda t: t * torch.sigmoid(1.702 * t)), (2, lambda t: F.gelu(t, approximate="tanh"))]:
         xf = x.float().clone().requires_grad_(True)
         r = fn(xf)
         r.backward(dy.float())
         assert rel(K.gelu_fwd(x.cuda(), kind).float(), r.detach()) < tol
         assert rel(K.gelu_bwd(x.cuda(), dy.cuda(), kind).float(), xf.grad) < tol * 2
     assert rel(K.add(x.cuda(), dy.cuda()).float(), x.float() + dy.float()) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_head_pad_and_bcast_add(K, dtype):
+    """plug-in tower glue: zero-padded heads (72 -> 128) and positions broadcast over images; both bit-exact copies/adds."""
+    rows, nh, d, dp = 37, 6, 72, 128
+    x = rnd((rows, nh * d), dtype, 51)
+    ref = torch.zeros(rows, nh, dp, dtype=dtype)
+    ref[:, :, :d] = x.view(rows, nh, d)
+    got = K.head_pad(x.cuda(), nh, d, dp)
+    assert torch.equal(got.cpu(), ref.view(rows, nh * dp))
+    back = K.head_pad(got, nh, d, dp, inverse=True)
+    assert torch.equal(back.cpu(), x)
+    n, L = 3, 16 * 72
+    a, b = rnd((n, L), dtype, 52), rnd((L,), dtype, 53)
+    y = K.bcast_add(a.cuda(), b.cuda())
+    assert torch.equal(y.cpu(), (a.float() + b.float()[None]).to(dtype))
+    # tanh-GELU as a GEMM epilogue
+    from multimeditron_amd._lib import EPI_GELU_TANH
+    A, W, bias = rnd((50, 64), dtype, 54), rnd((40, 64), dtype, 55), rnd((40,), dtype, 56)
+    r = F.gelu(A.float() @ W.float().t() + bias.float(), approximate="tanh")
+    o = K.linear_fwd(A.cuda(), W.cuda(), bias=bias.cuda(), act=EPI_GELU_TANH)
+    assert rel(o.float(), r) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

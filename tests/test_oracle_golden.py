@@ -7,7 +7,7 @@ import torch
 
 from oracle import ref_cpu as R
 
-MODELS = ["tiny_clip_llama", "tiny_clip_qwen2"]
+MODELS = ["tiny_clip_llama", "tiny_clip_qwen2", "tiny_siglip_qwen2"]   # the last: BASELINE config 5 plug-in (SigLIP tower)
 
 
 def rel(a, b):
@@ -24,6 +24,8 @@ def gold(request, golden_dir):
 @pytest.mark.parametrize("case", ["right", "left", "textonly", "interleaved4"])
 def test_forward_stages_logits_loss(gold, case):
     meta, w, v = gold
+    if case not in meta["cases"]:
+        pytest.skip(f"{meta['name']} holds no '{case}' case")
     batch = R.golden_batch(v, case)
     stages = {}
     with torch.no_grad():
@@ -68,5 +70,7 @@ def test_grads(gold):
 @pytest.mark.parametrize("T", [0.1, 0.7])
 def test_greedy_ids_bit_exact(gold, case, T):
     meta, w, v = gold
+    if case not in meta["cases"]:
+        pytest.skip(f"{meta['name']} holds no '{case}' case")
     ids = R.greedy_generate(w, R.golden_batch(v, case), meta, max_new_tokens=8, temperature=T)
     assert torch.equal(ids, v[f"{case}.greedy_T{T}"])

@@ -269,6 +269,162 @@ def model_fixture(name, llm_cfg, seed):
         print(name, "weights", sum(v.numel() for v in w.values()), "vector tensors", len(out))
 
 
+
+# ---- SigLIP plug-in (BASELINE config 5) ---------------------------------------------------------
+# The reference ships no SigLIP modality: config 5 plugs an alternate embedder in through
+# the reference's OWN plug-in protocol (BaseModalityConfig / BaseModalityProcessor / BaseModality + AutoModality.register,
+# base.py:10-196).  The class below is harness code written against that protocol; the arithmetic it pins is HF
+# transformers' SiglipVisionModel (.last_hidden_state = post_layernorm(encoder(...)), no CLS token, conv bias,
+# gelu_pytorch_tanh) followed by the reference's MLPProjector and the reference's splice + LLM.
+SIG = dict(hidden_size=144, intermediate_size=264, num_hidden_layers=2, num_attention_heads=2,   # head_dim 72, as so400m
+           image_size=56, patch_size=14, hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6)
+
+
+def register_siglip_plug():
+    from transformers import SiglipVisionModel
+    from multimeditron.model.modalities.base import AutoModality, BaseModality, BaseModalityConfig, BaseModalityProcessor
+    from multimeditron.model.projectors.mlp import MLPProjector
+    if "meditron_siglip" in AutoModality._registry:
+        return AutoModality._registry["meditron_siglip"].config_class
+
+    class SiglipImageConfig(BaseModalityConfig):
+        def __init__(self, hidden_size=4096, clip_name="google/siglip-so400m-patch14-384", **kwargs):
+            super().__init__(modality_type="image", hidden_size=hidden_size, **kwargs)
+            self.clip_name = clip_name
+
+    class SiglipImageProcessor(BaseModalityProcessor):
+        def process(self, modality):
+            raise NotImplementedError("fixtures feed pixel tensors directly")
+
+    @AutoModality.register("meditron_siglip")
+    class SiglipImageModality(BaseModality):
+        config_class = SiglipImageConfig
+        preprocessor_class = SiglipImageProcessor
+
+        def __init__(self, config):
+            super().__init__(config)
+            self.feature_extractor = SiglipVisionModel.from_pretrained(config.clip_name)
+            self.embedding_size = self.feature_extractor.config.hidden_size
+            self.projector = MLPProjector(self.embedding_size, config.hidden_size, dtype=self.dtype)
+
+        def forward(self, inputs):
+            x = torch.stack(inputs, dim=0).to(self.feature_extractor.device)
+            return self.projector(self.feature_extractor(pixel_values=x).last_hidden_state)
+
+        def freeze_modality_embedder(self):
+            for q in self.feature_extractor.parameters():
+                q.requires_grad = False
+
+        def unfreeze_modality_embedder(self):
+            for q in self.feature_extractor.parameters():
+                q.requires_grad = True
+
+        def unfreeze_projection(self):
+            for q in self.projector.parameters():
+                q.requires_grad = True
+
+    return SiglipImageConfig
+
+
+def siglip_fixture(name="tiny_siglip_qwen2", seed=300):
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    import multimeditron.model.model as mm
+    SiglipImageConfig = register_siglip_plug()
+    with tempfile.TemporaryDirectory() as tmp:
+        d1, d2 = os.path.join(tmp, "siglip"), os.path.join(tmp, "llm")
+        torch.manual_seed(seed)
+        SiglipVisionModel(SiglipVisionConfig(**SIG)).save_pretrained(d1)
+        qwen2_cfg().save_pretrained(d2)
+        cfg = MultimodalConfig(vocab_size=VOCAB, modalities=[SiglipImageConfig(hidden_size=128, clip_name=d1)],
+                               llm_path=d2, dtype="float32", eos_token_idx=EOS, hidden_size=128)
+        # the reference builds processors with AutoModality.preprocessor_from_name(..., config); ours takes the config
+        model = MultiModalModelForCausalLM(cfg)
+        g = torch.Generator().manual_seed(seed + 11)
+        with torch.no_grad():
+            seen = set()
+            for n, q in model.named_parameters():
+                if id(q) in seen:
+                    continue
+                seen.add(id(q))
+                if "layernorm" in n.lower() or "layer_norm" in n or n.endswith("norm.weight"):
+                    q.copy_((1.0 if n.endswith("weight") else 0.0) + 0.1 * torch.randn(q.shape, generator=g))
+                elif "probe" in n:
+                    q.copy_(0.06 * torch.randn(q.shape, generator=g))
+                elif q.ndim == 1:
+                    q.copy_(0.1 * torch.randn(q.shape, generator=g))
+                else:
+                    q.copy_(0.06 * torch.randn(q.shape, generator=g))
+                bf16_round_(q)
+        model = model.eval()
+        out = {}
+        mod = model.modalities_with_projection[0]
+        vm = mod.feature_extractor      # transformers 5.x: SiglipVisionModel holds embeddings/encoder/post_layernorm itself
+
+        def run(batch, tag, do_grads, do_generate):
+            acts, hooks = {}, []
+
+            def grab(key, pick=lambda o: o):
+                def fn(_m, _i, o):
+                    acts[key] = pick(o).detach().float().clone()
+                return fn
+            hooks.append(vm.embeddings.register_forward_hook(grab("vit_embeddings")))
+            hooks.append(vm.encoder.layers[0].register_forward_hook(grab("vit_layer0", lambda o: o[0] if isinstance(o, tuple) else o)))
+            hooks.append(vm.post_layernorm.register_forward_hook(grab("vit_last_hidden")))
+            hooks.append(mod.projector.register_forward_hook(grab("projector_out")))
+            hooks.append(model.model.model.layers[0].register_forward_hook(grab("llm_layer0", lambda o: o[0] if isinstance(o, tuple) else o)))
+            hooks.append(model.model.model.norm.register_forward_hook(grab("llm_final_norm")))
+            model.unfreeze()
+            model.zero_grad(set_to_none=True)
+            with torch.no_grad():
+                acts_sp = model.embed_modalities_with_text(batch["input_ids"], batch["processed_multimodal_inputs"]).float().clone()
+            o = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], position_ids=batch["position_ids"],
+                      labels=batch["labels"], processed_multimodal_inputs=batch["processed_multimodal_inputs"])
+            for hk in hooks:
+                hk.remove()
+            out[f"{tag}.logits"] = o.logits.detach().float()
+            out[f"{tag}.loss"] = o.loss.detach().float().reshape(1)
+            out[f"{tag}.act.spliced_embeds"] = acts_sp
+            for k, v in acts.items():
+                out[f"{tag}.act.{k}"] = v
+            if do_grads:
+                o.loss.backward()
+                keys = ("projector", "model.model.layers.0.", "model.model.embed_tokens", "model.model.norm",
+                        "feature_extractor.encoder.layers.1.", "feature_extractor.embeddings", "feature_extractor.post_layernorm")
+                for n, q in model.named_parameters():
+                    if q.grad is not None and any(k in n for k in keys):
+                        out[f"{tag}.grad.{n}"] = q.grad.detach().float().clone()
+                model.zero_grad(set_to_none=True)
+            for k in ("input_ids", "attention_mask", "position_ids", "labels"):
+                out[f"{tag}.in.{k}"] = batch[k].clone()
+            pmi = batch["processed_multimodal_inputs"]
+            out[f"{tag}.in.batch_idx"] = pmi["batch_idx"]["image"].clone()
+            out[f"{tag}.in.token_range"] = pmi["token_range"]["image"].clone()
+            out[f"{tag}.in.pixels"] = torch.stack(pmi["stacked"]["image"]).clone()
+            if do_generate:
+                for T in (0.1, 0.7):
+                    with torch.no_grad():
+                        ids = model.generate(batch, max_new_tokens=8, temperature=T, do_sample=False)
+                    out[f"{tag}.greedy_T{T}"] = ids.clone()
+
+        run(make_batch(seed + 1, 48, [[3], [2, 24]], "right"), "right", True, False)
+        run(make_batch(seed + 2, 48, [[4], [2, 22]], "left"), "left", False, True)
+        w = {}
+        for n, q in model.state_dict().items():
+            if ".head." in n or "position_ids" in n:      # pooling head: not on the token path
+                continue
+            w[n] = q.detach().to(torch.bfloat16).contiguous().clone()
+        save_file(w, os.path.join(OUT, f"{name}.weights.safetensors"))
+        save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(OUT, f"{name}.vectors.safetensors"))
+        llm = {k: v for k, v in qwen2_cfg().to_dict().items() if isinstance(v, (int, float, str, bool, dict, type(None), list))}
+        meta = dict(name=name, vision=dict(SIG, kind="siglip"), llm=llm, vocab_size=VOCAB, eos_token_idx=EOS, image_start=IMG_START,
+                    image_end=IMG_END, attachment=ATTACH, num_patches=P, transformers=transformers.__version__,
+                    torch=torch.__version__, cases=sorted({k.split(".")[0] for k in out}),
+                    note="SigLIP plug-in written against the reference's modality protocol (harness code in tools/make_golden.py); "
+                         "vision arithmetic = HF SiglipVisionModel, projector/splice/LLM = the reference")
+        with open(os.path.join(OUT, f"{name}.meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True, default=str)
+        print(name, "weights", sum(v.numel() for v in w.values()), "vector tensors", len(out))
+
 # ---- collator fixture ------------------------------------------------------------------------
 LLAMA3_TEMPLATE = (
     "{% for message in messages %}"
@@ -387,10 +543,12 @@ def collator_fixture():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["llama", "qwen2", "collator"]
+    which = sys.argv[1:] or ["llama", "qwen2", "siglip", "collator"]
     if "llama" in which:
         model_fixture("tiny_clip_llama", llama_cfg(), 100)
     if "qwen2" in which:
         model_fixture("tiny_clip_qwen2", qwen2_cfg(), 200)
+    if "siglip" in which:
+        siglip_fixture()
     if "collator" in which:
         collator_fixture()
