@@ -570,6 +570,77 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Skinny NT GEMM for KV-cache decode (reference model.py:595-602: one new token per sequence, M = batch <= 16).
+// C[M,N] = A[M,K] . W[N,K]^T is a stream over W (16 GB of bf16 weights per token for the 8B decoder): HBM-bound, so the
+// kernel is laid out for bytes in flight, not for MFMA occupancy.  One workgroup = 16 rows of W, its 8 waves split K;
+// a wave's lane reads 16 contiguous bytes of its W row straight into the MFMA operand layout (no LDS), 8 K-steps
+// (8 KiB per wave, 64 KiB per CU) in flight; x^T is the other operand, read through L2 (it is M*K*2 bytes, shared by
+// every workgroup); rows of x beyond M and rows of W beyond N are zeros from the buffer range check.  The 8 partial
+// 16x16 tiles are summed through LDS in a fixed order (deterministic) and wave 0 applies the epilogue.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
+  __shared__ float red[8][4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16;
+  const bf16* A = (const bf16*)g.A;
+  const bf16* B = (const bf16*)g.B;
+  const int nrows = min(16, g.N - n0);
+  auto rw = make_rsrc(B + (int64_t)n0 * g.ldb, (int64_t)nrows * g.ldb * 2);
+  auto rx = make_rsrc(A, (int64_t)g.M * g.lda * 2);
+  const int row = l & 15, kc = l >> 4;
+  const int nks = (g.K + 31) / 32;
+  const int per = (nks + 7) / 8;
+  const int ks0 = w * per, ks1 = min(nks, ks0 + per);
+  const unsigned wrow = (unsigned)(row * g.ldb) * 2u, xrow = (unsigned)(row * g.lda) * 2u;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;
+  for (int ks = ks0; ks < ks1; ks += U) {
+    u32x4 fw[U], fx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (ks + u) * 32 + kc * 8;
+      const bool ok = (ks + u) < ks1 && k < g.K;
+      fw[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? wrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, 0);
+      fx[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[u]), __builtin_bit_cast(bf16x8, fx[u]), acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][r][l] = acc[r];
+  __syncthreads();
+  if (w != 0) return;
+  // lane: m = l & 15, n = n0 + 4*(l>>4) + r
+  const int m = l & 15, n = n0 + 4 * (l >> 4);
+  if (m >= g.M || n >= g.N) return;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) t += red[ww][r][l];
+    v[r] = t;
+  }
+  const int epi = g.epi;
+  const bf16* bias = (const bf16*)g.bias;
+  const bf16* R = (const bf16*)g.residual;
+  bf16* cp = (bf16*)g.C + (int64_t)m * g.ldc + n;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (n + r >= g.N) break;
+    float t = v[r];
+    if (epi & MM_EPI_BIAS) t += (float)bias[n + r];
+    if (epi & MM_EPI_GELU_ERF) t = act_gelu_erf(t);
+    else if (epi & MM_EPI_QUICK_GELU) t = act_quick_gelu(t);
+    else if (epi & MM_EPI_GELU_TANH) t = act_gelu_tanh(t);
+    if (epi & MM_EPI_RESIDUAL) t += (float)R[(int64_t)m * g.ldr + n + r];
+    if (epi & MM_EPI_ACCUMULATE) t += (float)cp[r];
+    cp[r] = (bf16)t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // exact-fp32 GEMM (parity path).  64x64 tile, BK = 16, 4 waves each 32x32 (2x2 of 16x16x4 f32 MFMA).
 // LDS images are [k][x] for both operands (any global layout is re-tiled by scalar loads).
 // ------------------------------------------------------------------------------------------------------
@@ -699,6 +770,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
 
 static int g_opt_persist = 1;   // walk tiles with resident workgroups
 static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2..6 LDS-DMA tiles 256x128, 256x256, 128x128, 64x128, 64x64
+static int g_opt_skinny = 1;    // M <= 16 NT problems (decode) on the weight-streaming kernel
 static int g_opt_small = -1;    // experiments: force the DMA variant for problems that do not fill the chip (-1 = heuristic)
 // problems too small for the 256-wide tiles (ViT-L/14 on 4 images = 1028 rows, projector): these are latency-bound, so
 // the tile is chosen by how many workgroups it yields (tools/gemm_bench.py --small: 64x128 wins up to ~96 tiles of
@@ -718,6 +790,7 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!name) return MM_ERR_ARG;
   if (!strcmp(name, "attn_issue_waves")) return mm_attn_set_issue_waves(value);
   if (!strncmp(name, "attn_", 5)) return mm_attn_option(name, value);
+  if (!strcmp(name, "gemm_skinny")) { g_opt_skinny = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_small")) { if (value < -1 || value > 5) return MM_ERR_ARG; g_opt_small = value; return MM_OK; }
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
@@ -744,6 +817,13 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
       return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'b' ? 3 : 2));
     }();
     const int forced = g_opt_kernel ? g_opt_kernel : forced_env;
+    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 &&
+        (int64_t)16 * lda * 2 < 0xFFFFFFFFll && (int64_t)16 * ldb * 2 < 0xFFFFFFFFll) {   // decode: stream W once
+      dim3 grid((unsigned)((N + 15) / 16)), block(512);
+      hipLaunchKernelGGL(gemm_skinny_kernel, grid, block, 0, s, g);
+      MM_CHECK_LAUNCH();
+      return MM_OK;
+    }
     // the DMA kernels address a K-strided operand with 32-bit byte offsets over the whole matrix
     const bool fits32 = (layout == MM_GEMM_NT) || ((int64_t)K * ldb * 2 < 0xFFFFFFFFll && (layout != MM_GEMM_TN || (int64_t)K * lda * 2 < 0xFFFFFFFFll));
     const int64_t tiles_128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);

@@ -20,7 +20,9 @@ def _model(llm_name, clip_name, dtype="bfloat16", seed=1):
     from multimeditron_amd.model.presets import resolve_llm_config
     llm = resolve_llm_config(llm_name)
     torch.manual_seed(seed)
-    cfg = MultimodalConfig(vocab_size=llm["vocab_size"] + 2, modalities=[ImageConfig(hidden_size=llm["hidden_size"], clip_name=clip_name)],
+    from multimeditron_amd.model.modalities import SiglipImageConfig
+    mod_cls = SiglipImageConfig if "siglip" in clip_name else ImageConfig
+    cfg = MultimodalConfig(vocab_size=llm["vocab_size"] + 2, modalities=[mod_cls(hidden_size=llm["hidden_size"], clip_name=clip_name)],
                            llm_path=llm_name, dtype=dtype, eos_token_idx=128009, hidden_size=llm["hidden_size"])
     m = MultiModalModelForCausalLM(cfg, device="cuda")
     m.pack_parameters()
@@ -159,12 +161,13 @@ def test_config3_grad_accumulation_linearity_8b(big):
 
 
 def test_config5_qwen2_7b_shapes():
-    """Alternate LLM plug (Qwen2-7B: QKV bias, 28/4 heads, vocab 152064) behind the same modality API."""
+    """Alternate embedder + LLM plug (SigLIP-so400m/14@384: 729 tokens, no CLS, 16 heads x 72; Qwen2-7B: QKV bias,
+    28/4 heads, vocab 152064) behind the same modality API, at full size."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    m, llm = _model("Qwen/Qwen2-7B-Instruct", "openai/clip-vit-large-patch14")
+    m, llm = _model("Qwen/Qwen2-7B-Instruct", "google/siglip-so400m-patch14-384")
     V = llm["vocab_size"] + 2
-    b = _batch(1, 1024, 1, 256, V, 13)
+    b = _batch(1, 1024, 1, 729, V, 13, img=384)
     o = fwd(m, b)
     assert o.logits.shape == (1, 1024, V) and torch.isfinite(o.logits.float()).all()
     assert abs(float(o.loss) - math.log(V)) < 1.0

@@ -171,6 +171,24 @@ def test_gemm_dma_kernels_forced(K, variant, layout, shape):
     assert rel(out.float(), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("shape", [(1, 130, 64), (4, 6144, 4096), (16, 1000, 200), (7, 72, 1088), (3, 128258, 512)])
+def test_gemm_skinny_decode(K, shape):
+    """M <= 16 NT problems (one new token per sequence) take the weight-streaming kernel: ragged N / K, every epilogue."""
+    from multimeditron_amd._lib import EPI_GELU_ERF
+    M, N, Kd = shape
+    dtype = torch.bfloat16
+    a, w = rnd((M, Kd), dtype, 61), rnd((N, Kd), dtype, 62, 0.05)
+    bias, res = rnd((N,), dtype, 63), rnd((M, N), dtype, 64)
+    ref = a.float() @ w.float().t()
+    out = K.linear_fwd(a.cuda(), w.cuda(), ldc_pad=True)
+    assert rel(out.float(), ref) < TOL[dtype]
+    ref2 = F.gelu(ref + bias.float()) + res.float()
+    rp = torch.zeros(M, (N + 63) // 64 * 64, dtype=dtype)
+    rp[:, :N] = res
+    out2 = K.linear_fwd(a.cuda(), w.cuda(), bias=bias.cuda(), residual=rp.cuda()[:, :N], act=EPI_GELU_ERF, ldc_pad=True)
+    assert rel(out2.float(), ref2) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_asymmetric_identity(K, dtype):
     # A = I with an asymmetric B catches a transposed C write or a permuted fragment map

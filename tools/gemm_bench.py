@@ -66,6 +66,26 @@ def main():
                 print(f"{lay} M={M:6d} N={N:6d} K={Kd:6d}  {name}={v0}: {fl / med[v0] / 1e9:7.1f} TF/s   {name}={v1}: {fl / med[v1] / 1e9:7.1f} TF/s", flush=True)
         print("TOTAL ms", tot)
         return
+    if "--decode" in sys.argv:            # one token per sequence (M = 4): weight-streaming kernel vs the tiled one, GB/s of W
+        for (N, Kd) in [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336), (128258, 4096)]:
+            a, b = operands("NT", 4, N, Kd)
+            c = torch.empty(4, pad64(N), device="cuda", dtype=torch.bfloat16)[:, :N]
+            line = f"M=4 N={N:6d} K={Kd:5d} "
+            for mode in (0, 1):
+                set_opt("gemm_skinny", mode)
+                for _ in range(3):
+                    K.gemm(0, a, b, 4, N, Kd, out=c)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    K.gemm(0, a, b, 4, N, Kd, out=c)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                line += f"  {'skinny' if mode else 'tiled '} {ms * 1e3:7.1f} us {N * Kd * 2 / ms / 1e6:7.0f} GB/s"
+            print(line, flush=True)
+        set_opt("gemm_skinny", 1)
+        return
     if "--small" in sys.argv:             # ViT-L/14 (4 images = 1028 tokens) and projector shapes: every kernel variant, same process
         T2 = 1028
         shapes = {"NT": [(T2, 3072, 1024), (T2, 1024, 1024), (T2, 4096, 1024), (T2, 1024, 4096), (1024, 4096, 4096)],
