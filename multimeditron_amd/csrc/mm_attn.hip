@@ -1293,6 +1293,137 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq128_kernel(AttnArgs a) {
   }
 }
 
+// ============================================================================================================
+// KV-cache decode (ONE query token per sequence; reference model.py:595-602 with past_key_values).  The step reads the
+// whole K and V cache once -- 2*B*Skv*Hkv*D*2 bytes, ~34 MB per layer at B=4, S=2048 on the 8B decoder -- against a few
+// MFLOP, so it is laid out as an HBM stream: no MFMA, no LDS staging.  D/8 lanes share one key row (16 bytes each, one
+// coalesced 256-B row per 16 lanes at D = 128), the G query heads of a key/value head ride on the same K/V bytes, a
+// workgroup takes one slice of the keys of one (batch, kv head) with per-lane-group online softmax, and slices are
+// merged by a second tiny kernel (flash-decoding split-K), all in a fixed order (deterministic).
+// Partial record per (b, hq, split): [m (base-2 running max), l (sum), o[D]] in f32.
+// ============================================================================================================
+struct DecodeArgs {
+  const void *q, *k, *v;
+  int B, Skv, Hq, Hkv;
+  int64_t q_sb, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh;
+  const int64_t* kmask;
+  float scale;
+  void* out;
+  float* ws;
+  int nsplit, chunk;
+};
+
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(DecodeArgs a) {
+  constexpr int LPK = D / 8;            // lanes per key row
+  constexpr int KPI = 64 / LPK;         // keys per wave-instruction
+  constexpr int U = 4;                  // key rows in flight per lane (x2: K and V)
+  __shared__ float red[4][G][D + 2];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = l % LPK, grp = l / LPK;
+  const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+  const bf16* Kb = (const bf16*)a.k + b * a.k_sb + hkv * a.k_sh + sub * 8;
+  const bf16* Vb = (const bf16*)a.v + b * a.v_sb + hkv * a.v_sh + sub * 8;
+  const int kbeg = split * a.chunk, kend = min(a.Skv, kbeg + a.chunk);
+  const float sc = a.scale * LOG2E;
+
+  float qf[G][8], o[G][8], m[G], ls[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const bf16x8 qv = *(const bf16x8*)((const bf16*)a.q + b * a.q_sb + (hkv * G + g) * a.q_sh + sub * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { qf[g][j] = (float)qv[j] * sc; o[g][j] = 0.f; }
+    m[g] = -INFINITY;
+    ls[g] = 0.f;
+  }
+  for (int k0 = kbeg + w * KPI * U; k0 < kend; k0 += 4 * KPI * U) {
+    bf16x8 kf[U], vf[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = k0 + u * KPI + grp;
+      ok[u] = key < kend;
+      const int kk = ok[u] ? key : kbeg;                         // clamp: a valid address, result discarded
+      kf[u] = *(const bf16x8*)(Kb + (int64_t)kk * a.k_ss);
+      vf[u] = *(const bf16x8*)(Vb + (int64_t)kk * a.v_ss);
+      if (ok[u] && a.kmask) ok[u] = a.kmask[(int64_t)b * a.Skv + key] != 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float kx[8], vx[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kx[j] = (float)kf[u][j]; vx[j] = (float)vf[u][j]; }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float sv = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv = __builtin_fmaf(qf[g][j], kx[j], sv);
+#pragma unroll
+        for (int off = LPK / 2; off > 0; off >>= 1) sv += __shfl_xor(sv, off, 64);
+        if (ok[u]) {                                             // uniform over the LPK lanes of this key
+          const float mn = fmaxf(m[g], sv);
+          const float al = __builtin_amdgcn_exp2f(m[g] - mn), pv = __builtin_amdgcn_exp2f(sv - mn);
+          ls[g] = ls[g] * al + pv;
+          m[g] = mn;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[g][j] = __builtin_fmaf(pv, vx[j], o[g][j] * al);
+        }
+      }
+    }
+  }
+  // merge the KPI lane groups of the wave (same `sub`, different keys), then the 4 waves, in a fixed order
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int off = LPK; off < 64; off <<= 1) {
+      const float mo = __shfl_xor(m[g], off, 64), lo = __shfl_xor(ls[g], off, 64);
+      const float mn = fmaxf(m[g], mo);
+      const float a0 = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m[g] - mn), a1 = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mo - mn);
+      ls[g] = ls[g] * a0 + lo * a1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[g][j] = o[g][j] * a0 + __shfl_xor(o[g][j], off, 64) * a1;
+      m[g] = mn;
+    }
+    if (grp == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[w][g][sub * 8 + j] = o[g][j];
+      if (sub == 0) { red[w][g][D] = m[g]; red[w][g][D + 1] = ls[g]; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * D; i += 256) {
+    const int g = i / D, d = i % D;
+    float mn = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) mn = fmaxf(mn, red[ww][g][D]);
+    float lt = 0.f, ot = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const float al = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(red[ww][g][D] - mn);
+      lt += red[ww][g][D + 1] * al;
+      ot += red[ww][g][d] * al;
+    }
+    float* rec = a.ws + (((int64_t)b * a.Hq + hkv * G + g) * a.nsplit + split) * (D + 2);
+    rec[2 + d] = ot;
+    if (d == 0) { rec[0] = mn; rec[1] = lt; }
+  }
+}
+
+template <int D>
+__global__ void attn_decode_merge_kernel(const float* ws, int nsplit, bf16* out) {
+  const int row = blockIdx.x, d = threadIdx.x;          // row = b * Hq + hq
+  const float* rec = ws + (int64_t)row * nsplit * (D + 2);
+  float mn = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) mn = fmaxf(mn, rec[s * (D + 2)]);
+  float lt = 0.f, ot = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float al = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(rec[s * (D + 2)] - mn);
+    lt += rec[s * (D + 2) + 1] * al;
+    ot += rec[s * (D + 2) + 2 + d] * al;
+  }
+  out[(int64_t)row * D + d] = (bf16)(lt > 0.f ? ot / lt : 0.f);     // no visible key: 0, as in the prefill kernels
+}
+
 int g_attn_dkv_pair = 1;      // balanced paired dK/dV kernel (mm_set_option "attn_dkv_pair"; 0 = one key block per workgroup)
 int g_attn_issue_waves = 4;   // waves issuing the K/V DMA in the 8-wave D=128 kernels (mm_set_option "attn_issue_waves")
 
@@ -1433,4 +1564,42 @@ extern "C" int mm_attn_bwd(int dtype, const void* q, const void* k, const void* 
   }
   MM_CHECK_LAUNCH();
   return rc;
+}
+
+extern "C" int mm_attn_decode_splits(int B, int Hkv, int Skv) {
+  if (B <= 0 || Hkv <= 0 || Skv <= 0) return 1;
+  int n = (768 + B * Hkv - 1) / (B * Hkv);          // ~3 workgroups per CU
+  const int cap = (Skv + 63) / 64;                  // at least 64 keys per slice
+  if (n > cap) n = cap;
+  return n < 1 ? 1 : n;
+}
+
+extern "C" int mm_attn_decode(int dtype, const void* q, const void* k, const void* v, int B, int Skv, int Hq, int Hkv, int D,
+                              int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
+                              int64_t v_sh, const int64_t* key_mask, float scale, void* out, float* workspace, int nsplit,
+                              void* stream) {
+  if (B < 0 || Skv <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || nsplit < 1) return MM_ERR_ARG;
+  if (dtype != MM_BF16 || (D != 64 && D != 128)) return MM_ERR_UNSUPPORTED;
+  const int G = Hq / Hkv;
+  if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return MM_ERR_UNSUPPORTED;
+  if (!q || !k || !v || !out || !workspace) return MM_ERR_ARG;
+  if (B == 0) return MM_OK;
+  if ((q_sb | q_sh | k_sb | k_ss | k_sh | v_sb | v_ss | v_sh) & 7) return MM_ERR_ALIGN;
+  if (!mm_aligned16(q) || !mm_aligned16(k) || !mm_aligned16(v)) return MM_ERR_ALIGN;
+  DecodeArgs a{q, k, v, B, Skv, Hq, Hkv, q_sb, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, key_mask, scale, out, workspace, nsplit, 0};
+  a.chunk = (Skv + nsplit - 1) / nsplit;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(nsplit, Hkv, B), block(256);
+#define MM_DEC(DD, GG) hipLaunchKernelGGL((attn_decode_partial_kernel<DD, GG>), grid, block, 0, s, a)
+#define MM_DEC_G(DD)                                                                                          \
+  switch (G) { case 1: MM_DEC(DD, 1); break; case 2: MM_DEC(DD, 2); break; case 4: MM_DEC(DD, 4); break;     \
+               case 7: MM_DEC(DD, 7); break; default: MM_DEC(DD, 8); break; }
+  if (D == 128) { MM_DEC_G(128) } else { MM_DEC_G(64) }
+#undef MM_DEC_G
+#undef MM_DEC
+  MM_CHECK_LAUNCH();
+  if (D == 128) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(B * Hq), dim3(128), 0, s, workspace, nsplit, (bf16*)out);
+  else hipLaunchKernelGGL(attn_decode_merge_kernel<64>, dim3(B * Hq), dim3(64), 0, s, workspace, nsplit, (bf16*)out);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
 }

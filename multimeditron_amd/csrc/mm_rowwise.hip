@@ -459,39 +459,51 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, int V, int
 // to the storage type before comparison, so ties resolve exactly like torch.argmax over the softmax tensor
 // (first index wins).
 template <typename T>
-__global__ __launch_bounds__(256) void argmax_softmax_kernel(const T* logits, int V, int ld, float temperature, int64_t* out) {
-  __shared__ float red[8];
-  __shared__ float bestv[256];
-  __shared__ int besti[256];
-  const int row = blockIdx.x;
+__global__ __launch_bounds__(1024) void argmax_softmax_kernel(const T* logits, int V, int ld, float temperature, int64_t* out) {
+  constexpr int NT = 1024, NW = NT / 64;      // one row per block, 16 waves sweep the vocabulary three times
+  __shared__ float red[NW];
+  __shared__ float bestv[NW];
+  __shared__ int besti[NW];
+  const int row = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const T* p = logits + (int64_t)row * ld;
+  auto scaled = [&](int e) { return to_f32(from_f32<T>(to_f32(p[e]) / temperature)); };   // logits / T in the storage type
   float mx = -INFINITY;
-  for (int e = threadIdx.x; e < V; e += 256) mx = fmaxf(mx, to_f32(from_f32<T>(to_f32(p[e]) / temperature)));
-  mx = block_max_256(mx, red);
+  for (int e = threadIdx.x; e < V; e += NT) mx = fmaxf(mx, scaled(e));
+  mx = wave_max(mx);
+  if (l == 0) red[w] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) mx = fmaxf(mx, red[i]);
+  __syncthreads();
   float sm = 0.f;
-  for (int e = threadIdx.x; e < V; e += 256) sm += expf(to_f32(from_f32<T>(to_f32(p[e]) / temperature)) - mx);
-  sm = block_sum_256(sm, red);
+  for (int e = threadIdx.x; e < V; e += NT) sm += expf(scaled(e) - mx);
+  sm = wave_sum(sm);
+  if (l == 0) red[w] = sm;
+  __syncthreads();
+  sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) sm += red[i];
   float bv = -1.f;
   int bi = 0x7FFFFFFF;
-  for (int e = threadIdx.x; e < V; e += 256) {
-    const float pr = to_f32(from_f32<T>(expf(to_f32(from_f32<T>(to_f32(p[e]) / temperature)) - mx) / sm));
+  for (int e = threadIdx.x; e < V; e += NT) {
+    const float pr = to_f32(from_f32<T>(expf(scaled(e) - mx) / sm));
     if (pr > bv) { bv = pr; bi = e; }
   }
-  bestv[threadIdx.x] = bv;
-  besti[threadIdx.x] = bi;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const float ov = bestv[threadIdx.x + s];
-      const int oi = besti[threadIdx.x + s];
-      if (ov > bestv[threadIdx.x] || (ov == bestv[threadIdx.x] && oi < besti[threadIdx.x])) {
-        bestv[threadIdx.x] = ov;
-        besti[threadIdx.x] = oi;
-      }
-    }
-    __syncthreads();
+  // first index wins among equal probabilities: (value desc, index asc) order in every merge
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
-  if (threadIdx.x == 0) out[row] = besti[0];
+  if (l == 0) { bestv[w] = bv; besti[w] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < NW; ++i)
+      if (bestv[i] > bv || (bestv[i] == bv && besti[i] < bi)) { bv = bestv[i]; bi = besti[i]; }
+    out[row] = bi;
+  }
 }
 
 // ---------------------------------------------------------------- cast
@@ -732,9 +744,9 @@ extern "C" int mm_argmax_softmax(int dtype, const void* logits, int rows, int V,
   if (!logits || !out || rows < 0 || V <= 0 || ld < V || !(temperature > 0.f)) return MM_ERR_ARG;
   if (rows == 0) return MM_OK;
   if (dtype == MM_BF16)
-    hipLaunchKernelGGL(argmax_softmax_kernel<bf16>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)logits, V, ld, temperature, out);
+    hipLaunchKernelGGL(argmax_softmax_kernel<bf16>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16*)logits, V, ld, temperature, out);
   else
-    hipLaunchKernelGGL(argmax_softmax_kernel<float>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)logits, V, ld, temperature, out);
+    hipLaunchKernelGGL(argmax_softmax_kernel<float>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const float*)logits, V, ld, temperature, out);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

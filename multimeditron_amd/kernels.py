@@ -259,6 +259,23 @@ def attn_bwd(q, k, v, out, dout, lse, key_mask, causal, scale, dq, dk, dv):
          *_strides3(k), *_strides3(v), _p(key_mask), int(causal), float(scale), _p(dq), _p(dk), _p(dv), _p(delta), _stream())
 
 
+def attn_decode_supported(q_dtype, Hq, Hkv, D):
+    return q_dtype == torch.bfloat16 and D in (64, 128) and Hq % Hkv == 0 and (Hq // Hkv) in (1, 2, 4, 7, 8)
+
+
+def attn_decode(q, k, v, key_mask, scale):
+    """One query token per sequence over a KV cache: q [B,Hq,D] (strided view ok), k/v [B,Skv,Hkv,D] -> out [B,Hq,D]."""
+    B, Hq, D = q.shape
+    Skv, Hkv = k.shape[1], k.shape[2]
+    assert q.stride(2) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    ns = _lib.lib().mm_attn_decode_splits(B, Hkv, Skv)
+    ws = torch.empty(B * Hq * ns * (D + 2), dtype=torch.float32, device=q.device)
+    out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
+    call("mm_attn_decode", dt(q), _p(q), _p(k), _p(v), B, Skv, Hq, Hkv, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+         k.stride(2), v.stride(0), v.stride(1), v.stride(2), _p(key_mask), float(scale), _p(out), _p(ws), ns, _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ activations
 def swiglu_fwd(gu, I):
     M = gu.shape[0]

@@ -145,6 +145,9 @@ class LayerKVCache:
         self.k[:, self.len:self.len + S].copy_(kn)      # device-side memory plumbing
         self.v[:, self.len:self.len + S].copy_(vn)
         self.len += S
+        if S == 1 and K.attn_decode_supported(qkv.dtype, Hq, Hkv, D):      # decode step: stream the cache once (split-K)
+            out = K.attn_decode(q.view(B, Hq, D), self.k[:, : self.len], self.v[:, : self.len], key_mask, D ** -0.5)
+            return out.view(B, Hq * D)
         out, _ = K.attn_fwd(q, self.k[:, : self.len], self.v[:, : self.len], key_mask, True, D ** -0.5)
         return out.view(B * S, Hq * D)
 

@@ -312,6 +312,33 @@ def test_attention_fwd_bwd(K, dtype, case):
     assert rel(dv.float(), vf.grad) < gtol, "dv"
 
 
+@pytest.mark.parametrize("case", [(4, 2051, 32, 8, 128, True), (2, 77, 4, 2, 64, True), (1, 300, 7, 1, 128, False),
+                                  (3, 64, 2, 2, 64, False), (2, 1, 8, 1, 128, False), (2, 513, 16, 2, 128, True)])
+def test_attention_decode(K, case):
+    """one query token over a KV cache (split-K stream kernel) == the prefill kernel's last row == the fp32 reference"""
+    B, Skv, Hq, Hkv, D, masked = case
+    dtype = torch.bfloat16
+    Smax = Skv + 5                                     # the cache is a longer buffer; the step sees a prefix view
+    kc, vc = rnd((B, Smax, Hkv, D), dtype, 71), rnd((B, Smax, Hkv, D), dtype, 72)
+    qkv = rnd((B, (Hq + 2 * Hkv) * D), dtype, 73)       # q is a strided view of the fused projection output
+    q = qkv[:, : Hq * D].view(B, Hq, D)
+    mask = None
+    if masked:
+        mask = torch.ones(B, Skv, dtype=torch.long)
+        mask[0, : Skv // 3] = 0
+        if B > 1:
+            mask[1, 5:9] = 0
+    scale = D ** -0.5
+    ref = attn_ref(q.float().unsqueeze(1), kc[:, :Skv].float(), vc[:, :Skv].float(), mask, True, scale)[:, 0]
+    kd, vd, qd = kc.cuda(), vc.cuda(), qkv.cuda()
+    out = K.attn_decode(qd[:, : Hq * D].view(B, Hq, D), kd[:, :Skv], vd[:, :Skv], mask.cuda() if masked else None, scale)
+    torch.cuda.synchronize()
+    assert out.shape == (B, Hq, D)
+    assert rel(out.float(), ref) < TOL[dtype]
+    pre, _ = K.attn_fwd(qd[:, : Hq * D].view(B, 1, Hq, D), kd[:, :Skv], vd[:, :Skv], mask.cuda() if masked else None, True, scale)
+    assert rel(out.float(), pre.view(B, Hq, D).float()) < TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("H", [128, 1024, 4096])
 def test_norms(K, dtype, H):
