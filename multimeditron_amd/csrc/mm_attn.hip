@@ -651,7 +651,7 @@ __device__ __forceinline__ int imgb_swz(int row) { return ((row & 3) << 2) | ((r
 __device__ __forceinline__ int imgb_off(int row, int ch) { return 256 * row + 16 * (ch ^ imgb_swz(row)); }
 
 // DMA ROWS rows x 256 B (row stride in elements) starting at matrix row `row0`; 8 waves, ROWS/32 pieces (4 rows) each
-template <int ROWS, int NW = 8>
+template <int ROWS, int NW = 8, int NWV_UNUSED = 8>
 __device__ __forceinline__ void imgb_dma(unsigned tile_lds, const SRsrc& rs, int64_t stride, int row0) {
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -726,15 +726,17 @@ __device__ __forceinline__ void attn_work_item(int id, int nblk, int B, int Hq, 
   }
 }
 
-template <int INW>
-__global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
+// NWV waves per workgroup (8: 256 query rows, one workgroup per CU; 4: 128 rows, two independent workgroups per CU)
+template <int INW, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void attn_fwd128_kernel(AttnArgs a) {
+  constexpr int QB = NWV * 32;
   constexpr int BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, h = l >> 5;
   int qblk, b, hq;
-  attn_work_item(blockIdx.x, (a.Sq + 255) / 256, a.B, a.Hq, a.Hkv, a.causal != 0, qblk, b, hq);
+  attn_work_item(blockIdx.x, (a.Sq + QB - 1) / QB, a.B, a.Hq, a.Hkv, a.causal != 0, qblk, b, hq);
   const int hkv = hq / (a.Hq / a.Hkv);
-  const int q0 = qblk * 256 + w * 32;
+  const int q0 = qblk * QB + w * 32;
   const int qi = q0 + (l & 31);
   const int shift = a.Skv - a.Sq;
   const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
@@ -758,13 +760,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128_kernel(AttnArgs a) {
 
   int ntiles = (a.Skv + BKV - 1) / BKV;
   if (a.causal) {
-    const int qmax = min(a.Sq - 1, qblk * 256 + 255) + shift;
+    const int qmax = min(a.Sq - 1, qblk * QB + QB - 1) + shift;
     ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
   }
   auto issue = [&](int t) {
     const unsigned st = lds0 + (unsigned)((t & 1) * 2 * TILE);
-    imgb_dma<BKV, INW>(st, rk, a.k_ss, t * BKV);
-    imgb_dma<BKV, INW>(st + TILE, rv, a.v_ss, t * BKV);
+    imgb_dma<BKV, INW, NWV>(st, rk, a.k_ss, t * BKV);
+    imgb_dma<BKV, INW, NWV>(st + TILE, rv, a.v_ss, t * BKV);
   };
   if (ntiles > 0) issue(0);
   for (int t = 0; t < ntiles; ++t) {
@@ -1424,6 +1426,7 @@ __global__ void attn_decode_merge_kernel(const float* ws, int nsplit, bf16* out)
   out[(int64_t)row * D + d] = (bf16)(lt > 0.f ? ot / lt : 0.f);     // no visible key: 0, as in the prefill kernels
 }
 
+int g_attn_fwd_waves = 8;     // waves per workgroup of the D=128 forward (mm_set_option "attn_fwd_waves": 8 or 4)
 int g_attn_dkv_pair = 1;      // balanced paired dK/dV kernel (mm_set_option "attn_dkv_pair"; 0 = one key block per workgroup)
 int g_attn_issue_waves = 4;   // waves issuing the K/V DMA in the 8-wave D=128 kernels (mm_set_option "attn_issue_waves")
 
@@ -1436,16 +1439,20 @@ template <int D>
 int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
   if (D == 128 && !attn_use_v1()) {
     const size_t lds = 2 * 2 * 64 * 256;
-    const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;     // 1-D grid: attn_work_item orders the blocks
+    const int qb = g_attn_fwd_waves * 32;
+    const int64_t nwg = (int64_t)((a.Sq + qb - 1) / qb) * a.Hq * a.B;     // 1-D grid: attn_work_item orders the blocks
     if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
-    dim3 grid((unsigned)nwg), block(512);
-    if (g_attn_issue_waves == 4) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_fwd128_kernel<4>, grid, block, lds, s, a);
-    } else {
-      (void)hipFuncSetAttribute((const void*)attn_fwd128_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_fwd128_kernel<8>, grid, block, lds, s, a);
-    }
+    dim3 grid((unsigned)nwg), block(g_attn_fwd_waves * 64);
+#define MM_FWD128(...)                                                                                                  \
+  do {                                                                                                                  \
+    auto kfn = attn_fwd128_kernel<__VA_ARGS__>;                                                                         \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+    hipLaunchKernelGGL(kfn, grid, block, lds, s, a);                                                                    \
+  } while (0)
+    if (g_attn_fwd_waves == 4) MM_FWD128(4, 4);
+    else if (g_attn_issue_waves == 4) MM_FWD128(4, 8);
+    else MM_FWD128(8, 8);
+#undef MM_FWD128
     return MM_OK;
   }
   const size_t lds = 2 * 64 * D * 2;
@@ -1497,6 +1504,7 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
 
 int mm_attn_option(const char* name, int value) {   // reached through mm_set_option (mm_gemm.hip)
   if (!strcmp(name, "attn_dkv_pair")) { g_attn_dkv_pair = value != 0; return MM_OK; }
+  if (!strcmp(name, "attn_fwd_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_attn_fwd_waves = value; return MM_OK; }
   return MM_ERR_ARG;
 }
 

@@ -41,6 +41,15 @@ if "--ab-pair" in sys.argv:      # dK/dV: one key block per workgroup vs the bal
         run(4, 2048, 32, 8, 128, True)
     run(2, 4096, 32, 8, 128, True)
     sys.exit(0)
+if "--ab-fwdwaves" in sys.argv:  # forward: one 8-wave workgroup per CU vs two independent 4-wave workgroups (same process)
+    for v in (8, 4, 8, 4):
+        lib().mm_set_option(b"attn_fwd_waves", v)
+        print("attn_fwd_waves", v)
+        run(4, 2048, 32, 8, 128, True)
+    run(2, 4096, 32, 8, 128, True)
+    lib().mm_set_option(b"attn_fwd_waves", 8)
+    run(2, 4096, 32, 8, 128, True)
+    sys.exit(0)
 if "--quick" in sys.argv:
     run(4, 2048, 32, 8, 128, True)
     run(4, 2048, 32, 8, 128, True)
