@@ -26,7 +26,10 @@ class DataCollatorForMultimodal:
     use_2d_position_ids: bool = False
     return_tensors: str = "pt"
     pin_memory: bool = False
+    num_threads: int = 0          # > 1: load + preprocess the batch's attachments on a thread pool (PIL decode / resize release
+                                  # the GIL); results keep the sample order, so the batch is identical to the sequential one
     _pre: Any = field(default=None, init=False, repr=False)
+    _pool: Any = field(default=None, init=False, repr=False)
 
     def __call__(self, features, return_tensors=None):
         rt = return_tensors or self.return_tensors
@@ -47,8 +50,11 @@ class DataCollatorForMultimodal:
     @torch.no_grad()
     def torch_call(self, raw_features: List[Dict[str, Any]]) -> Dict[str, Any]:
         pre = self._preprocessor()
-        loaded = [BaseModalityLoader.load_modalities(f, self.modality_loaders) for f in raw_features]
-        features = pre.tokenize(pre.process_modality_to_tensor(loaded), add_generation_prompt=self.add_generation_prompt)
+        if self.num_threads > 1:
+            features = pre.tokenize(self._load_and_process_parallel(pre, raw_features), add_generation_prompt=self.add_generation_prompt)
+        else:
+            loaded = [BaseModalityLoader.load_modalities(f, self.modality_loaders) for f in raw_features]
+            features = pre.tokenize(pre.process_modality_to_tensor(loaded), add_generation_prompt=self.add_generation_prompt)
 
         batch: Dict[str, Any] = {k: torch.stack([s[k] for s in features]) for k in ("input_ids", "labels", "attention_mask")}
         batch["modalities"] = [s[MODALITIES_KEY] for s in features]
@@ -82,6 +88,29 @@ class DataCollatorForMultimodal:
                   "implement your own collator, or modify the model to accept custom position_ids per modality.")
         batch["position_ids"] = position_ids
         return batch
+
+    def _load_and_process_parallel(self, pre, raw_features):
+        """Same result as load_modalities + process_modality_to_tensor, one task per attachment."""
+        from concurrent.futures import ThreadPoolExecutor
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=self.num_threads)
+
+        def one(m):
+            loader = self.modality_loaders.get(m[MODALITY_TYPE_KEY])
+            if loader is None:
+                raise ValueError(f"Modality loader for type '{m[MODALITY_TYPE_KEY]}' not found.")
+            mm = m.copy()
+            mm[MODALITY_VALUE_KEY] = loader(m)
+            return pre.modality_processors[m[MODALITY_TYPE_KEY]].process(mm)
+
+        futs = [[self._pool.submit(one, m) for m in f.get(MODALITIES_KEY, [])] if MODALITIES_KEY in f else None for f in raw_features]
+        out = []
+        for f, fl in zip(raw_features, futs):
+            s = f.copy()
+            if fl is not None:
+                s[MODALITIES_KEY] = [x.result() for x in fl]
+            out.append(s)
+        return out
 
     @staticmethod
     def _position_ids_2d(position_ids, features):

@@ -47,13 +47,15 @@ def env(golden_dir, tmp_path_factory):
     return meta, vec, make_tok, proc, ct, os.path.join(golden_dir, "mock_dataset")
 
 
+@pytest.mark.parametrize("threads", [0, 4])      # 4: attachments loaded + preprocessed on a thread pool, same batch
 @pytest.mark.parametrize("side", ["right", "left"])
 @pytest.mark.parametrize("gen", [False, True])
-def test_conversation_batches(env, side, gen):
+def test_conversation_batches(env, side, gen, threads):
     meta, vec, make_tok, proc, ct, imgdir = env
     coll = DataCollatorForMultimodal(tokenizer=make_tok(side), modality_processors={"image": proc},
                                      modality_loaders={"image": AutoModalityLoader.from_name("fs-image", base_path=imgdir)},
-                                     attachment_token=meta["attachment_token"], chat_template=ct, add_generation_prompt=gen)
+                                     attachment_token=meta["attachment_token"], chat_template=ct, add_generation_prompt=gen,
+                                     num_threads=threads)
     b = coll(copy.deepcopy(meta["samples_conv"]))
     tag = f"conv_{side}_gen{int(gen)}"
     for k in ("input_ids", "labels", "attention_mask", "position_ids"):
