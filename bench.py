@@ -185,7 +185,15 @@ def main():
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ       # torchrun with one rank still rehearses the RCCL path
     if use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        opts = None
+        try:      # RCCL kernels on a high-priority stream: they take freed CUs ahead of queued GEMM workgroups
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:
+            opts = None
+        if opts is not None:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from multimeditron_amd.model.model import MultimodalConfig, MultiModalModelForCausalLM
     from multimeditron_amd.model.modalities import ImageConfig, SiglipImageConfig

@@ -100,6 +100,13 @@ class MultimodalTrainer:
         force = bool(os.environ.get("MM_FORCE_EXCHANGE")) and self.dist is not None    # rehearse RCCL calls with 1 rank
         self.exchanger = GradExchanger(flat.grad, [(s, e) for s, e, _ in self.ranges], segs, self.bucket_elems,
                                        dist=self.dist if (self.world > 1 or force) else None, group=self.pg, force=force)
+        if self.world > 1 and not os.environ.get("MM_GEMM_PERSIST"):
+            # The GEMM's persistent grid is one resident workgroup per CU, each walking 1/256 of the tiles.  While an RCCL
+            # kernel holds some CUs (its waves and an 8-wave GEMM workgroup do not fit one CU together), the workgroups that
+            # find no CU start only when another one exits -- at the very end -- and the launch takes up to twice as long.
+            # One tile per workgroup lets the dispatcher hand tiles to whichever CUs are free (measured neutral at 1 GPU).
+            from .._lib import lib
+            lib().mm_set_option(b"gemm_persist", 0)
 
     # ------------------------------------------------------------------ reference surface
     def compute_loss(self, model, inputs, return_outputs=False, **kwargs):
