@@ -135,15 +135,24 @@ int mm_attn_bwd(int dtype, const void* q, const void* k, const void* v, const vo
                 int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, const int64_t* key_mask, int causal,
                 float scale, void* dq, void* dk, void* dv, float* delta, void* stream);
 
+/* Decode step: mm_rope_apply on the q and k heads of x [T, (Hq+2Hkv)*D] (row stride ld) plus, in the same pass, the append
+ * of the roped k heads and the v heads to the KV cache (HF cache update inside LlamaAttention.forward, HF:llama:247-252):
+ * kdst / vdst point at the cache row of this step for sequence 0 ([Hkv, D] contiguous), dstride = elements between
+ * consecutive sequences' rows (one token per sequence: T = batch).                                                   */
+int mm_rope_append(int dtype, void* x, int T, int Hq, int Hkv, int D, int ld, const float* cos_t, const float* sin_t,
+                   void* kdst, void* vdst, int64_t dstride, void* stream);
+
 /* KV-cache decode step: ONE query token per sequence over the cached keys (reference model.py:595-602 calling the LLM with
  * past_key_values; HF:llama:217-281 with q_len = 1).  q [B,Hq,D] (strides q_sb,q_sh; D contiguous), k/v [B,Skv,Hkv,D] as
  * in mm_attn_fwd, key_mask [B,Skv] or NULL, out [B,Hq,D] contiguous.  MM_BF16, D in {64,128}, Hq/Hkv in {1,2,4,7,8}.
  * workspace: f32 [B*Hq*nsplit*(D+2)] with nsplit = mm_attn_decode_splits(B,Hkv,Skv) (slices of the keys, merged in a
- * fixed order).  Rows with no visible key give 0.                                                              */
+ * fixed order).  sync: int [B*Hkv], zero on entry and left zero -- the slice that arrives last does the merge inside
+ * the same launch; NULL = merge in a second launch.  Rows with no visible key give 0.                              */
 int mm_attn_decode_splits(int B, int Hkv, int Skv);
 int mm_attn_decode(int dtype, const void* q, const void* k, const void* v, int B, int Skv, int Hq, int Hkv, int D,
                    int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
-                   int64_t v_sh, const int64_t* key_mask, float scale, void* out, float* workspace, int nsplit, void* stream);
+                   int64_t v_sh, const int64_t* key_mask, float scale, void* out, float* workspace, int nsplit, int* sync,
+                   void* stream);
 
 /* ---- activations -----------------------------------------------------------------------------------------
  * SwiGLU: HF:llama:163-176.  gu [M, 2I] = [gate | up] from the fused gate/up GEMM; out [M,I] = silu(gate)*up     */

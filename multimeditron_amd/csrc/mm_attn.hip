@@ -1313,6 +1313,7 @@ struct DecodeArgs {
   void* out;
   float* ws;
   int nsplit, chunk;
+  int* sync;            // [B*Hkv] arrival counters, zero on entry and left zero (NULL: merge in a second launch)
 };
 
 template <int D, int G>
@@ -1408,6 +1409,34 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(DecodeArgs a) 
     float* rec = a.ws + (((int64_t)b * a.Hq + hkv * G + g) * a.nsplit + split) * (D + 2);
     rec[2 + d] = ot;
     if (d == 0) { rec[0] = mn; rec[1] = lt; }
+  }
+  if (a.sync == nullptr) return;
+  // the slice that arrives LAST merges all slices of this (batch, kv head) -- in slice order, so the result does not
+  // depend on which one that is -- and leaves the counter at zero for the next step
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = atomicAdd(a.sync + b * a.Hkv + hkv, 1);
+    last = old == a.nsplit - 1;
+    if (last) a.sync[b * a.Hkv + hkv] = 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  for (int i = threadIdx.x; i < G * D; i += 256) {
+    const int g = i / D, d = i % D;
+    const int64_t row = (int64_t)b * a.Hq + hkv * G + g;
+    const float* rec = a.ws + row * a.nsplit * (D + 2);
+    float mn = -INFINITY;
+    for (int sp = 0; sp < a.nsplit; ++sp) mn = fmaxf(mn, __builtin_nontemporal_load(rec + sp * (D + 2)));
+    float lt = 0.f, ot = 0.f;
+    for (int sp = 0; sp < a.nsplit; ++sp) {
+      const float al = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(__builtin_nontemporal_load(rec + sp * (D + 2)) - mn);
+      lt += __builtin_nontemporal_load(rec + sp * (D + 2) + 1) * al;
+      ot += __builtin_nontemporal_load(rec + sp * (D + 2) + 2 + d) * al;
+    }
+    ((bf16*)a.out)[row * D + d] = (bf16)(lt > 0.f ? ot / lt : 0.f);
   }
 }
 
@@ -1585,7 +1614,7 @@ extern "C" int mm_attn_decode_splits(int B, int Hkv, int Skv) {
 extern "C" int mm_attn_decode(int dtype, const void* q, const void* k, const void* v, int B, int Skv, int Hq, int Hkv, int D,
                               int64_t q_sb, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss,
                               int64_t v_sh, const int64_t* key_mask, float scale, void* out, float* workspace, int nsplit,
-                              void* stream) {
+                              int* sync, void* stream) {
   if (B < 0 || Skv <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || nsplit < 1) return MM_ERR_ARG;
   if (dtype != MM_BF16 || (D != 64 && D != 128)) return MM_ERR_UNSUPPORTED;
   const int G = Hq / Hkv;
@@ -1594,7 +1623,7 @@ extern "C" int mm_attn_decode(int dtype, const void* q, const void* k, const voi
   if (B == 0) return MM_OK;
   if ((q_sb | q_sh | k_sb | k_ss | k_sh | v_sb | v_ss | v_sh) & 7) return MM_ERR_ALIGN;
   if (!mm_aligned16(q) || !mm_aligned16(k) || !mm_aligned16(v)) return MM_ERR_ALIGN;
-  DecodeArgs a{q, k, v, B, Skv, Hq, Hkv, q_sb, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, key_mask, scale, out, workspace, nsplit, 0};
+  DecodeArgs a{q, k, v, B, Skv, Hq, Hkv, q_sb, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, key_mask, scale, out, workspace, nsplit, 0, sync};
   a.chunk = (Skv + nsplit - 1) / nsplit;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(nsplit, Hkv, B), block(256);
@@ -1606,6 +1635,7 @@ extern "C" int mm_attn_decode(int dtype, const void* q, const void* k, const voi
 #undef MM_DEC_G
 #undef MM_DEC
   MM_CHECK_LAUNCH();
+  if (sync) return MM_OK;
   if (D == 128) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(B * Hq), dim3(128), 0, s, workspace, nsplit, (bf16*)out);
   else hipLaunchKernelGGL(attn_decode_merge_kernel<64>, dim3(B * Hq), dim3(64), 0, s, workspace, nsplit, (bf16*)out);
   MM_CHECK_LAUNCH();

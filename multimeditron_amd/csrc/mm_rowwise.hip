@@ -282,6 +282,39 @@ __global__ void rope_apply_kernel(T* x, int Tn, int nheads, int D, int ld, const
   *(Vec16<T>*)(p + half) = ob;
 }
 
+// decode step: RoPE on the q and k heads of the fused projection output AND the append of the roped k / the v heads to
+// the KV cache in the same pass (x [T, (Hq+2Hkv)*D] with row stride ld; kdst/vdst = the cache row of this step for
+// sequence 0, dstride = elements between sequences)
+template <typename T>
+__global__ void rope_append_kernel(T* x, int Tn, int Hq, int Hkv, int D, int ld, const float* cs, const float* sn, T* kdst, T* vdst,
+                                   int64_t dstride) {
+  constexpr int VN = Vec16<T>::N;
+  const int half = D / 2, per_head = half / VN, nh = Hq + 2 * Hkv;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Tn * nh * per_head) return;
+  const int jc = (int)(i % per_head);
+  const int h = (int)((i / per_head) % nh);
+  const int t = (int)(i / ((int64_t)per_head * nh));
+  T* p = x + (int64_t)t * ld + h * D + jc * VN;
+  Vec16<T> a = *(Vec16<T>*)p, b = *(Vec16<T>*)(p + half), oa = a, ob = b;
+  if (h < Hq + Hkv) {
+    const float* c = cs + (int64_t)t * half + jc * VN;
+    const float* s = sn + (int64_t)t * half + jc * VN;
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+      oa.set(k, a.get(k) * c[k] - b.get(k) * s[k]);
+      ob.set(k, b.get(k) * c[k] + a.get(k) * s[k]);
+    }
+    *(Vec16<T>*)p = oa;
+    *(Vec16<T>*)(p + half) = ob;
+  }
+  if (h >= Hq) {
+    T* d = (h < Hq + Hkv ? kdst + (h - Hq) * D : vdst + (h - Hq - Hkv) * D) + (int64_t)t * dstride + jc * VN;
+    *(Vec16<T>*)d = oa;
+    *(Vec16<T>*)(d + half) = ob;
+  }
+}
+
 // ---------------------------------------------------------------- SwiGLU / GELU / add
 template <typename T>
 __global__ void swiglu_fwd_kernel(const T* gu, int M, int I, T* out) {
@@ -629,6 +662,23 @@ extern "C" int mm_rope_apply(int dtype, void* x, int T, int nheads, int D, int l
     hipLaunchKernelGGL(rope_apply_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (bf16*)x, T, nheads, D, ld, cos_t, sin_t, inverse);
   else
     hipLaunchKernelGGL(rope_apply_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)x, T, nheads, D, ld, cos_t, sin_t, inverse);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_rope_append(int dtype, void* x, int T, int Hq, int Hkv, int D, int ld, const float* cos_t, const float* sin_t,
+                              void* kdst, void* vdst, int64_t dstride, void* stream) {
+  if (!x || !cos_t || !sin_t || !kdst || !vdst || T < 0 || Hq <= 0 || Hkv <= 0 || D <= 0) return MM_ERR_ARG;
+  if (dtype != MM_BF16 && dtype != MM_F32) return MM_ERR_UNSUPPORTED;
+  if (T == 0) return MM_OK;
+  const int vn = dtype == MM_BF16 ? 8 : 4;
+  if ((D / 2) % vn || (ld % vn) || (dstride % vn) || !mm_aligned16(x) || !mm_aligned16(kdst) || !mm_aligned16(vdst)) return MM_ERR_ALIGN;
+  const int64_t total = (int64_t)T * (Hq + 2 * Hkv) * (D / 2 / vn);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == MM_BF16)
+    hipLaunchKernelGGL(rope_append_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (bf16*)x, T, Hq, Hkv, D, ld, cos_t, sin_t, (bf16*)kdst, (bf16*)vdst, dstride);
+  else
+    hipLaunchKernelGGL(rope_append_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)x, T, Hq, Hkv, D, ld, cos_t, sin_t, (float*)kdst, (float*)vdst, dstride);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

@@ -231,6 +231,14 @@ def rope_apply_(x, T, nheads, D, ld, cos, sin, inverse=False):
     return x
 
 
+def rope_append_(qkv, B, Hq, Hkv, D, cos, sin, kcache, vcache, pos):
+    """decode step: RoPE q/k in place + write roped k and v to cache[:, pos] ([B, Smax, Hkv, D] contiguous in the last two)."""
+    assert kcache.stride(3) == 1 and kcache.stride(2) == D and vcache.stride(2) == D and kcache.stride(0) == vcache.stride(0)
+    call("mm_rope_append", dt(qkv), _p(qkv), B, Hq, Hkv, D, qkv.stride(0), _p(cos), _p(sin), _p(kcache[:, pos]), _p(vcache[:, pos]),
+         kcache.stride(0), _stream())
+    return qkv
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _strides3(t):  # t: [B, S, H, D] view
     assert t.dim() == 4 and t.stride(3) == 1
@@ -271,8 +279,12 @@ def attn_decode(q, k, v, key_mask, scale):
     ns = _lib.lib().mm_attn_decode_splits(B, Hkv, Skv)
     ws = torch.empty(B * Hq * ns * (D + 2), dtype=torch.float32, device=q.device)
     out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
+    # sync=None: the slices are merged by a second (tiny) launch.  The single-launch form (last-arriving slice merges;
+    # `sync` counters) is correct but SLOWER on MI355X: its device-scope fences write back / invalidate the XCD's whole L2
+    # once per workgroup (8.2 vs 5.2 ms/token on the 8B decoder), so it is not used.
+    sync = None
     call("mm_attn_decode", dt(q), _p(q), _p(k), _p(v), B, Skv, Hq, Hkv, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-         k.stride(2), v.stride(0), v.stride(1), v.stride(2), _p(key_mask), float(scale), _p(out), _p(ws), ns, _stream())
+         k.stride(2), v.stride(0), v.stride(1), v.stride(2), _p(key_mask), float(scale), _p(out), _p(ws), ns, _p(sync), _stream())
     return out
 
 

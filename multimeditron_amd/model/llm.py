@@ -111,7 +111,33 @@ class DecoderLayer(nn.Module):
         self.input_layernorm = Norm(cfg.hidden_size, cfg.rms_norm_eps, bias=False, dtype=dtype, device=device)
         self.post_attention_layernorm = Norm(cfg.hidden_size, cfg.rms_norm_eps, bias=False, dtype=dtype, device=device)
 
+    @torch.no_grad()
+    def decode_step(self, x, cos, sin, key_mask, B, cache):
+        """One new token per sequence (generate's decode loop, reference model.py:595-602): the four linears take the
+        weight-streaming GEMM (M <= 16), RoPE and the cache append are one pass, attention is the split-K stream over the
+        cache.  Same arithmetic and rounding points as forward().  (Folding RMSNorm / SwiGLU into the GEMM's x operand was
+        measured SLOWER: every workgroup redoes the transform on all 64 lanes and the kernel turns VALU-bound, 43 vs 27 us
+        and 57 vs 25 us per launch, so they stay separate launches.)"""
+        a, m = self.self_attn, self.mlp
+        Hq, Hkv, D = a.Hq, a.Hkv, a.D
+        h, _ = K.rmsnorm_fwd(x, self.input_layernorm.weight, self.input_layernorm.eps)
+        qkv = K.linear_fwd(h, a._wqkv.tensor(), bias=a._bqkv.tensor() if a._bqkv is not None else None)
+        K.rope_append_(qkv, B, Hq, Hkv, D, cos, sin, cache.k, cache.v, cache.len)
+        cache.len += 1
+        o = K.attn_decode(qkv[:, : Hq * D].view(B, Hq, D), cache.k[:, : cache.len], cache.v[:, : cache.len], key_mask, D ** -0.5)
+        x = K.linear_fwd(o.view(B, Hq * D), a.o_proj.weight, residual=x)
+        h, _ = K.rmsnorm_fwd(x, self.post_attention_layernorm.weight, self.post_attention_layernorm.eps)
+        act = K.swiglu_fwd(K.linear_fwd(h, m._wgu.tensor()), m.I)
+        return K.linear_fwd(act, m.down_proj.weight, residual=x)
+
+    def can_decode_step(self, x, B, S, cache):
+        a = self.self_attn
+        return (cache is not None and S == 1 and B <= 16 and x.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and K.attn_decode_supported(x.dtype, a.Hq, a.Hkv, a.D))
+
     def forward(self, x, cos, sin, key_mask, B, S, cache=None):
+        if self.can_decode_step(x, B, S, cache):
+            return self.decode_step(x, cos, sin, key_mask, B, cache)
         a = self.self_attn
         h, x = self.input_layernorm(x)
         qkv = Fm.linear(h, a._wqkv, a._bqkv, dummy=grad_dummy(a.q_proj.weight))

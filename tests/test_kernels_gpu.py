@@ -189,6 +189,25 @@ def test_gemm_skinny_decode(K, shape):
     assert rel(out2.float(), ref2) < TOL[dtype]
 
 
+def test_rope_append(K):
+    B, Hq, Hkv, D, Smax, pos = 3, 4, 2, 64, 10, 6
+    dtype = torch.bfloat16
+    W = (Hq + 2 * Hkv) * D
+    qkv = rnd((B, W), dtype, 87).cuda()
+    cos, sin = torch.cos(rnd((B, D // 2), torch.float32, 88)).cuda(), torch.sin(rnd((B, D // 2), torch.float32, 88)).cuda()
+    ref = qkv.clone()
+    K.rope_apply_(ref, B, Hq + Hkv, D, W, cos, sin)
+    kc = torch.zeros(B, Smax, Hkv, D, dtype=dtype, device="cuda")
+    vc = torch.zeros_like(kc)
+    got = qkv.clone()
+    K.rope_append_(got, B, Hq, Hkv, D, cos, sin, kc, vc, pos)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert torch.equal(kc[:, pos].reshape(B, -1), ref[:, Hq * D:(Hq + Hkv) * D])
+    assert torch.equal(vc[:, pos].reshape(B, -1), ref[:, (Hq + Hkv) * D:])
+    assert float(kc[:, :pos].abs().sum()) == 0 and float(kc[:, pos + 1:].abs().sum()) == 0
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_asymmetric_identity(K, dtype):
     # A = I with an asymmetric B catches a transposed C write or a permuted fragment map
@@ -337,6 +356,20 @@ def test_attention_decode(K, case):
     assert rel(out.float(), ref) < TOL[dtype]
     pre, _ = K.attn_fwd(qd[:, : Hq * D].view(B, 1, Hq, D), kd[:, :Skv], vd[:, :Skv], mask.cuda() if masked else None, True, scale)
     assert rel(out.float(), pre.view(B, Hq, D).float()) < TOL[dtype]
+    # single-launch form of the ABI (the slice that arrives last merges; counters stay zero): bit-identical result
+    from multimeditron_amd._lib import call, lib
+    qv, kv, vv = qd[:, : Hq * D].view(B, Hq, D), kd[:, :Skv], vd[:, :Skv]
+    ns = lib().mm_attn_decode_splits(B, Hkv, Skv)
+    ws = torch.empty(B * Hq * ns * (D + 2), dtype=torch.float32, device="cuda")
+    sync = torch.zeros(B * Hkv, dtype=torch.int32, device="cuda")
+    out1 = torch.empty_like(out)
+    mg = mask.cuda() if masked else None
+    for _ in range(2):
+        call("mm_attn_decode", 0, qv.data_ptr(), kv.data_ptr(), vv.data_ptr(), B, Skv, Hq, Hkv, D, qv.stride(0), qv.stride(1),
+             kv.stride(0), kv.stride(1), kv.stride(2), vv.stride(0), vv.stride(1), vv.stride(2), mg.data_ptr() if masked else None,
+             float(scale), out1.data_ptr(), ws.data_ptr(), ns, sync.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out) and int(sync.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
