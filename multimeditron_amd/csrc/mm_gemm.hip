@@ -205,7 +205,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-        *(bf16x4*)cp = o;
+        *(bf16x4*)cp = o;      // default cache policy: non-temporal stores here measured -4 % (tools/build_diag.sh)
       } else {
         for (int r = 0; r < 4; ++r)
           if (n + r < g.N) cp[r] = (bf16)v[r];

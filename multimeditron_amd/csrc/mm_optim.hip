@@ -123,7 +123,10 @@ extern "C" int mm_adamw_step(int dtype, void* p, const void* g, float* master, f
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   if (!mm_aligned16(p) || !mm_aligned16(g) || !mm_aligned16(master) || !mm_aligned16(m) || !mm_aligned16(v)) return MM_ERR_ALIGN;
   const int64_t nv4 = (n / 4 + 255) / 256;
-  const unsigned nb = (unsigned)(nv4 < 1 ? 1 : (nv4 < 2048 ? nv4 : 2048));
+  // grid cap: the update runs on a side stream under the next step's forward; MM_ADAMW_BLOCKS throttles how much of the
+  // chip (and of HBM) it takes while the forward's GEMMs run
+  static const int64_t cap = [] { const char* e = getenv("MM_ADAMW_BLOCKS"); const long c = e ? atol(e) : 0; return (int64_t)(c > 0 ? c : 2048); }();
+  const unsigned nb = (unsigned)(nv4 < 1 ? 1 : (nv4 < cap ? nv4 : cap));
   static const bool nt = [] { const char* e = getenv("MM_ADAMW_NT"); return !e || e[0] != '0'; }();
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MM_BF16) {
