@@ -22,7 +22,7 @@ import torch.nn as nn
 from .. import functional as Fm
 from .. import kernels as K
 from ..nn import FlatParams, grad_dummy
-from ..utils import get_torch_dtype
+from ..utils import get_torch_dtype, trace_range
 from .llm import CausalLM, CausalLMOutput, LLMConfig
 from .modalities import AutoModality, BaseModality, BaseModalityConfig, BaseModalityProcessor
 from .presets import resolve_llm_config
@@ -307,7 +307,8 @@ class MultiModalModelForCausalLM(nn.Module):
             if len(stack) == 0:
                 continue
             modality = self._get_modality_by_name(name)
-            e = modality(stack, stages=stages) if stages is not None else modality(stack)
+            with trace_range(f"modality:{name}"):
+                e = modality(stack, stages=stages) if stages is not None else modality(stack)
             projs.append(e.reshape(-1, e.shape[-1]))
             bis.append(pmi["batch_idx"][name].to(dev))
             trs.append(pmi["token_range"][name].to(dev))
@@ -316,7 +317,8 @@ class MultiModalModelForCausalLM(nn.Module):
             proj = projs[0] if len(projs) == 1 else torch.cat(projs, dim=0)
             bi = (bis[0] if len(bis) == 1 else torch.cat(bis)).to(torch.int64).contiguous()
             tr = (trs[0] if len(trs) == 1 else torch.cat(trs)).to(torch.int64).contiguous()
-        out = Fm.embed_splice(emb, input_ids, proj, bi, tr, B, S, dummy=grad_dummy(emb))
+        with trace_range("embed_splice"):
+            out = Fm.embed_splice(emb, input_ids, proj, bi, tr, B, S, dummy=grad_dummy(emb))
         return out.view(B, S, -1)
 
     def forward(self, input_ids: torch.LongTensor = None, inputs_embeds: Optional[torch.Tensor] = None,
@@ -335,9 +337,10 @@ class MultiModalModelForCausalLM(nn.Module):
             labels = labels[:, :msl] if labels is not None else None
             attention_mask = attention_mask[:, :msl] if attention_mask is not None else None
             position_ids = position_ids[:, :msl] if position_ids is not None else None
-        return self.model(inputs_embeds=inputs_embeds, attention_mask=attention_mask, position_ids=position_ids,
-                          past_key_values=past_key_values, use_cache=use_cache, labels=labels, return_dict=return_dict,
-                          **kwargs)
+        with trace_range("decoder+loss"):
+            return self.model(inputs_embeds=inputs_embeds, attention_mask=attention_mask, position_ids=position_ids,
+                              past_key_values=past_key_values, use_cache=use_cache, labels=labels, return_dict=return_dict,
+                              **kwargs)
 
     def generate(self, batch: Dict[str, Any], max_new_tokens=512, temperature=0.1, do_sample=True, **kwargs) -> torch.Tensor:
         """model.py:528-640: KV-cache decode.  Token choice = argmax(softmax(logits/T)) (one kernel) or a per-row

@@ -19,6 +19,8 @@ from typing import Any, Dict, Iterable, List, Optional
 
 import torch
 
+from ..utils import trace_range
+
 from .. import functional as Fm
 from .. import kernels as K
 from .exchange import GradExchanger
@@ -127,11 +129,13 @@ class MultimodalTrainer:
         ex.begin_step(exchange_this_step=last)
         Fm.set_grad_ready_hook(lambda p: ex.on_ready(id(p)))
         try:
-            loss = self.compute_loss(self.model, inputs)
+            with trace_range("forward"):
+                loss = self.compute_loss(self.model, inputs)
             # mean over micro-batches and ranks (HF Trainer with model_accepts_loss_kwargs=False, trainer.py:80)
             self._wait_optimizer()      # the previous update still reads the flat gradient buffer on the side stream
             if loss.requires_grad:      # e.g. ALIGNMENT mode on a text-only micro-batch: nothing trainable is on the path
-                loss.backward(gradient=torch.full_like(loss, 1.0 / (self.accum * self.world)))
+                with trace_range("backward(+gradient exchange)"):
+                    loss.backward(gradient=torch.full_like(loss, 1.0 / (self.accum * self.world)))
         finally:
             Fm.set_grad_ready_hook(None)
         self._micro += 1
@@ -142,8 +146,9 @@ class MultimodalTrainer:
                 if getattr(seg.param, "_mm_fresh", False):
                     self.flat.grad[seg.start:seg.end].zero_()
                     seg.param._mm_fresh = False
-            ex.finish_step()
-            self._optimizer_step()
+            with trace_range("exchange tail + clip + AdamW launch"):
+                ex.finish_step()
+                self._optimizer_step()
             self._micro = 0
         else:
             ex.finish_step()
