@@ -36,6 +36,7 @@ struct GemmArgs {
   const void* residual; int ldr;
   int epi;
   int nbm, nbn;
+  int tail;   // persistent 256x256 grid only: the last `tail` tiles are each cut into two 256x128 halves (see the kernel)
 };
 
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -463,10 +464,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   // the LDS ring, so the first DMA of the next tile is already in flight while this tile's epilogue stores run, and
   // there is no per-tile dispatch / prologue bubble.  (tile id) & 7 == blockIdx.x & 7, so the XCD grouping of
   // block_to_tile is preserved.
+  // WAVE QUANTISATION.  T tiles on a 256-workgroup persistent grid take ceil(T/256) rounds: 384 tiles (the 8B model's
+  // q/k/v wgrad) run 2 rounds at 75 % occupancy, 896 (down_proj wgrad) 4 rounds at 87.5 %.  When the remainder R = T mod
+  // grid is at most half the grid, the last R tiles are each cut into two 256x128 halves (g.tail = R), handed to
+  // workgroups 0 .. 2R-1 after their full tiles: R half-rounds instead of one more full round, no cross-workgroup sum.
+  const int total_full = total - g.tail;
   int tile = blockIdx.x;
-  if (tile >= total) return;
-  int pm, pn;
-  block_to_tile(tile, g.nbm, g.nbn, pm, pn);
+  int pm = 0, pn = 0;
+  if (tile < total_full) block_to_tile(tile, g.nbm, g.nbn, pm, pn);
   int m0 = pm * BM_, n0 = pn * BN_;
   SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
   SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
@@ -493,8 +498,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   };
   static_assert(STAGES == 2, "the persistent stream below is written for the 2-stage ring");
   int sidx = 0;                                                       // global K-step counter (ring position)
-  issue(ra, rb, 0, 0);
-  while (true) {
+  if (tile < total_full) issue(ra, rb, 0, 0);
+  while (tile < total_full) {
     f32x4 acc[MREP][NREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
     const int next = tile + gridDim.x;
     int nm0 = 0, nn0 = 0;
     SRsrc nra = ra, nrb = rb;
-    if (next < total) {
+    if (next < total_full) {
       int qm, qn;
       block_to_tile(next, g.nbm, g.nbn, qm, qn);
       nm0 = qm * BM_;
@@ -520,10 +525,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
 #if defined(MM_GEMM_DIAG_NODMA)
 #elif defined(MM_GEMM_DIAG_HOTK)
       if (t + 1 < nk) issue(ra, rb, 0, (sidx + 1) & 1);
-      else if (next < total) issue(ra, rb, 0, (sidx + 1) & 1);
+      else if (next < total_full) issue(ra, rb, 0, (sidx + 1) & 1);
 #else
       if (t + 1 < nk) issue(ra, rb, t + 1, (sidx + 1) & 1);
-      else if (next < total) issue(nra, nrb, 0, (sidx + 1) & 1);
+      else if (next < total_full) issue(nra, nrb, 0, (sidx + 1) & 1);
 #endif
       // 4 phases of (MREP/2 x NREP) MFMAs; the fragments of phase p+1 are requested BEFORE phase p's MFMAs are issued, so
       // inside a wave the LDS latency of all but the first phase hides under 16 MFMAs (+1.3 % over read-then-multiply).
@@ -560,12 +565,78 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
       }
     }
     gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
-    if (next >= total) break;
     tile = next;
     m0 = nm0;
     n0 = nn0;
     ra = nra;
     rb = nrb;
+  }
+  // ---- the half-tile round (256 x BN/2): same A tile and image, B tile of half the rows; not chained to the stream above
+  if constexpr (BM_ == 256 && BN_ == 256 && (NREP % 2) == 0) {
+    if (g.tail > 0 && (int)blockIdx.x < 2 * g.tail) {
+      constexpr int BNH = BN_ / 2, NREPH = NREP / 2, HM = MREP / 2;
+      constexpr bool INVH = INV && (BNH / (8 * ISSUE_WAVES)) % 4 == 0;
+      int hm, hn;
+      block_to_tile(total_full + ((int)blockIdx.x >> 1), g.nbm, g.nbn, hm, hn);
+      const int hm0 = hm * BM_, hn0 = hn * BN_ + ((int)blockIdx.x & 1) * BNH;
+      const SRsrc ha = tile_rsrc<A_KC>(A, g.lda, hm0, g.M, g.K);
+      const SRsrc hb = tile_rsrc<B_KC>(B, g.ldb, hn0, g.N, g.K);
+      unsigned offbh[INVH ? BNH / (8 * ISSUE_WAVES) : 1];
+      if constexpr (INVH) dma_offsets<B_KC, BNH, ISSUE_WAVES>(offbh, g.ldb);
+      auto issue_h = [&](int t, int stage) {
+        const unsigned st = lds0 + (unsigned)(stage * STAGE_BYTES);
+        if constexpr (INVH) {
+          if (t < nk_full) {
+            dma_tile_inv<BM_, ISSUE_WAVES>(st, ha, offa, (unsigned)t * sa);
+            dma_tile_inv<BNH, ISSUE_WAVES>(st + A_BYTES, hb, offbh, (unsigned)t * sb);
+            return;
+          }
+        }
+        dma_tile<A_KC, BM_, ISSUE_WAVES>(st, ha, g.lda, t * G_BK, g.K);
+        dma_tile<B_KC, BNH, ISSUE_WAVES>(st + A_BYTES, hb, g.ldb, t * G_BK, g.K);
+      };
+      f32x4 acch[MREP][NREPH];
+#pragma unroll
+      for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREPH; ++j) acch[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_s_barrier();            // every wave has left the ring of the last full tile
+      issue_h(0, 0);
+      for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* cur = smem + (t & 1) * STAGE_BYTES;
+        if (t + 1 < nk) issue_h(t + 1, (t + 1) & 1);
+        bf16x8 fbq[2][NREPH], faq[2][HM];
+#pragma unroll
+        for (int j = 0; j < NREPH; ++j) fbq[0][j] = frag_load2<B_KC, BNH>(cur + A_BYTES, wn * NREPH + j, 0);
+#pragma unroll
+        for (int i = 0; i < HM; ++i) faq[0][i] = frag_load2<A_KC, BM_>(cur, wm * MREP + i, 0);
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          const int ks = ph >> 1, hf = ph & 1;
+          if (ph < 3) {
+            const int nks = (ph + 1) >> 1, nhf = (ph + 1) & 1;
+            if (nhf == 0) {
+#pragma unroll
+              for (int j = 0; j < NREPH; ++j) fbq[nks & 1][j] = frag_load2<B_KC, BNH>(cur + A_BYTES, wn * NREPH + j, nks);
+            }
+#pragma unroll
+            for (int i = 0; i < HM; ++i) faq[(ph + 1) & 1][i] = frag_load2<A_KC, BM_>(cur, wm * MREP + nhf * HM + i, nks);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < HM; ++i)
+#pragma unroll
+            for (int j = 0; j < NREPH; ++j)
+              acch[hf * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbq[ks & 1][j], faq[ph & 1][i], acch[hf * HM + i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      gemm_epilogue<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
+    }
   }
 }
 
@@ -770,6 +841,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
 
 static int g_opt_persist = 1;   // walk tiles with resident workgroups
 static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2..6 LDS-DMA tiles 256x128, 256x256, 128x128, 64x128, 64x64
+static int g_opt_tail = 1;      // cut the tiles of a less-than-half-full last round into 256x128 halves (persistent 256x256 grid)
 static int g_opt_skinny = 1;    // M <= 16 NT problems (decode) on the weight-streaming kernel
 static int g_opt_small = -1;    // experiments: force the DMA variant for problems that do not fill the chip (-1 = heuristic)
 // problems too small for the 256-wide tiles (ViT-L/14 on 4 images = 1028 rows, projector): these are latency-bound, so
@@ -790,6 +862,7 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!name) return MM_ERR_ARG;
   if (!strcmp(name, "attn_issue_waves")) return mm_attn_set_issue_waves(value);
   if (!strncmp(name, "attn_", 5)) return mm_attn_option(name, value);
+  if (!strcmp(name, "gemm_tail")) { g_opt_tail = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_skinny")) { g_opt_skinny = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_small")) { if (value < -1 || value > 5) return MM_ERR_ARG; g_opt_small = value; return MM_OK; }
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
@@ -806,7 +879,7 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
   if ((epilogue & MM_EPI_BIAS) && !bias) return MM_ERR_ARG;
   if ((epilogue & MM_EPI_RESIDUAL) && !residual) return MM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, 0, 0};
+  GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, 0, 0, 0};
   if (dtype == MM_BF16) {
     if ((lda & 7) || (ldb & 7) || (ldc & 3) || ((epilogue & MM_EPI_RESIDUAL) && (ldr & 3))) return MM_ERR_ALIGN;
     if (!mm_aligned16(A) || !mm_aligned16(B) || (((uintptr_t)C) & 7)) return MM_ERR_ALIGN;
@@ -844,7 +917,14 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
       const size_t lds = 2 * (bm + bn) * G_BK * 2;
       static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
       // persistent: one resident workgroup per CU walks the tiles; otherwise one tile each
-      const int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
+      int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
+      if (g_opt_persist && g_opt_tail && variant == 2) {       // wave quantisation: see the kernel
+        const int64_t rem = nwg % ncu;
+        if (rem > 0 && 2 * rem <= ncu) {
+          g.tail = (int)rem;
+          nblk = nwg >= ncu ? ncu : 2 * rem;
+        }
+      }
       dim3 grid((unsigned)nblk), block(512);
 #define MM_LAUNCH_ONE(...)                                                                                               \
   do {                                                                                                                   \

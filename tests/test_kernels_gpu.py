@@ -171,6 +171,43 @@ def test_gemm_dma_kernels_forced(K, variant, layout, shape):
     assert rel(out.float(), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("layout", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("shape", [(6144, 4096, 256), (4352, 4100, 192), (300, 520, 200)])
+def test_gemm_half_tile_round(K, layout, shape):
+    """persistent 256x256 grid: 384 tiles (1 round + 128 tiles cut into 256x128 halves), 17x17 tiles with a ragged N edge
+    (1 round + 33 -> halves), and a 2x3-tile problem (halves only); A/B against the plain persistent schedule."""
+    from multimeditron_amd._lib import lib
+    M, N, Kd = shape
+    dtype = torch.bfloat16
+    pad8 = lambda n: (n + 7) // 8 * 8
+    a, b = rnd((M, Kd), dtype, 91), rnd((N, Kd), dtype, 92)
+    ref = a.float() @ b.float().t()
+
+    def padded(x):
+        r, c = x.shape
+        o = torch.zeros(r, pad8(c), dtype=dtype)
+        o[:, :c] = x
+        return o.cuda()[:, :c]
+    if layout == "NT":
+        A, B, lay = padded(a), padded(b), 0
+    elif layout == "NN":
+        A, B, lay = padded(a), padded(b.t().contiguous()), 1
+    else:
+        A, B, lay = padded(a.t().contiguous()), padded(b.t().contiguous()), 2
+    outs = []
+    assert lib().mm_set_option(b"gemm_kernel", 3) == 0
+    try:
+        for tail in (1, 0):
+            assert lib().mm_set_option(b"gemm_tail", tail) == 0
+            outs.append(K.gemm(lay, A, B, M, N, Kd, ldc_pad=True).clone())
+        torch.cuda.synchronize()
+    finally:
+        lib().mm_set_option(b"gemm_kernel", 0)
+        lib().mm_set_option(b"gemm_tail", 1)
+    assert rel(outs[0].float(), ref) < TOL[dtype]
+    assert torch.equal(outs[0], outs[1])        # same products in the same K order: bit-identical to the unsplit schedule
+
+
 @pytest.mark.parametrize("shape", [(1, 130, 64), (4, 6144, 4096), (16, 1000, 200), (7, 72, 1088), (3, 128258, 512)])
 def test_gemm_skinny_decode(K, shape):
     """M <= 16 NT problems (one new token per sequence) take the weight-streaming kernel: ragged N / K, every epilogue."""
