@@ -99,8 +99,22 @@ def measure_gemm_roofline(trainer, batch):
         K.gemm = orig
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
     tot_fl = sum(f for _, _, f, _ in rec)
+    alg_bytes = sum(2.0 * (M * Kd + N * Kd + M * N) for _, _, _, (_, M, N, Kd) in rec)      # A, B, C once, bf16
     return dict(launches=len(rec), avg_launch_ms=tot_ms / max(1, len(rec)), flops_per_launch=tot_fl / max(1, len(rec)),
-                achieved_tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0, gemm_ms_per_step=tot_ms)
+                achieved_tflops=tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0, gemm_ms_per_step=tot_ms,
+                algorithmic_bytes_per_launch=alg_bytes / max(1, len(rec)))
+
+
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed PMC passes of this same command (tools/profile_round.sh ->
+    profiles/r01_pmc_traffic.json): counters cannot be collected from inside the timed process, so `traffic` is the figure of
+    those separate rocprofv3 --pmc runs (null when the file is absent or the workload differs)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def cpu_baseline(llm, vis, hidden, workload, budget_layers=8, S=1024, B=2):
@@ -252,7 +266,12 @@ def main():
             roof = {"bound": "mfma", "kernel": "gemm_bf16_dma_kernel (NT/NN/TN; every bf16 mm_gemm launch of the step)", "achieved": round(r["achieved_tflops"], 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(r["achieved_tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": r["launches"], "avg_launch_ms": round(r["avg_launch_ms"], 4),
-                    "flops_per_launch": r["flops_per_launch"], "gemm_ms_per_step": round(r["gemm_ms_per_step"], 2)}
+                    "flops_per_launch": r["flops_per_launch"], "gemm_ms_per_step": round(r["gemm_ms_per_step"], 2),
+                    "algorithmic_bytes_per_launch": round(r["algorithmic_bytes_per_launch"])}
+            pt = pmc_traffic()
+            if pt is not None and args.workload == "llama31_8b_vitl14_s2048_b4" and args.mode == "FULL":
+                roof["traffic"] = round(pt["bytes_per_launch"])       # HBM bytes per launch, same averaging as `achieved`
+                roof["traffic_source"] = "profiles/r01_pmc_traffic.json: " + pt["method"]
             if fps is not None:
                 roof["whole_step_achieved"] = round(step_tf, 2)
                 roof["whole_step_frac"] = round(step_tf / PEAK_BF16_TFLOPS, 4)

@@ -20,7 +20,7 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"
   timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv --pmc $pass -d $O/pmc/$n -o r -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_$n.json 2> $O/pmc_$n.err
   echo "pmc $n done"
 done
-python3 $R/tools/pmc_summary.py $O/pmc > $O/pmc_summary.md
+python3 $R/tools/pmc_summary.py $O/pmc $O/pmc_traffic.json > $O/pmc_summary.md
 find $O -name "*.csv" -size +2M -delete
 rm -rf $O/pmc/*/*/*kernel_trace* 2>/dev/null || true
 echo done
