@@ -671,6 +671,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
     for (int u = 0; u < U; ++u) {
       const int k = (ks + u) * 32 + kc * 8;
       const bool ok = (ks + u) < ks1 && k < g.K;
+      // default cache policy on W: the non-temporal one (aux = 2) measured 5.4 vs 5.1 ms/token on the 8B decoder
       fw[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? wrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, 0);
       fx[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, 0);
     }
