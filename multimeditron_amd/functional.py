@@ -43,6 +43,57 @@ def _ready(p):
         _grad_ready_hook(p)
 
 
+# ---- deferred weight gradients ---------------------------------------------------------------------------------------
+# The modality backward (ViT-L/14 on 4 images: ~700 short, latency-bound launches) runs at the very end of backward with
+# nothing beside it.  Weight-gradient GEMMs have no consumer inside backward, so those of the LAST decoder layers to run
+# (layers 0..n-1) are held back and launched on a side stream when backward reaches the embedding splice: they fill the
+# CUs the modality backward leaves idle.  Same kernels, same operands, same single write per parameter.
+_defer = None
+
+
+def set_wgrad_deferral(stream, params):
+    """stream: side HIP stream for the deferred GEMMs; params: the first Parameter of every deferred group (held weakly).
+    stream=None disables."""
+    import weakref
+    global _defer
+    _defer = None if stream is None else {"stream": stream, "params": {id(p): weakref.ref(p) for p in params}, "items": [],
+                                          "event": None}
+
+
+def _is_deferred(p):
+    r = _defer["params"].get(id(p)) if _defer is not None else None
+    return r is not None and r() is p        # the weak reference guards against id() reuse by a later model
+
+
+def flush_deferred_wgrads():
+    """Launch what has been held back (no-op when nothing is pending); returns the event the compute stream must wait for
+    before gradients are read (or None)."""
+    d = _defer
+    if d is None:
+        return None
+    if d["items"]:
+        from ._lib import lib
+        main, side = torch.cuda.current_stream(), d["stream"]
+        side.wait_stream(main)
+        lib().mm_set_option(b"gemm_persist", 0)      # one tile per workgroup: shares the chip with the other stream's kernels
+        try:
+            with torch.cuda.stream(side):
+                for dy, x, wg in d["items"]:
+                    dy.record_stream(side)
+                    x.record_stream(side)
+                    g, acc = wg.grad_target()
+                    K.linear_wgrad(dy, x, g, acc)
+                    wg.ready()
+                ev = torch.cuda.Event()
+                ev.record(side)
+        finally:
+            lib().mm_set_option(b"gemm_persist", int(d.get("persist", 1)))
+        d["items"].clear()
+        d["event"] = ev
+    ev, d["event"] = d["event"], None
+    return ev
+
+
 class ParamGroup:
     """One or several Parameters that are adjacent views of one flat buffer and act as a single GEMM operand
     (fused q/k/v, fused gate/up).  `.tensor()` is the fused [sum_out, in] weight (or [sum_out] bias)."""
@@ -132,9 +183,12 @@ class LinearFn(torch.autograd.Function):
             K.colsum(dy, g, acc)
             bg.ready()
         if wg.requires_grad:
-            g, acc = wg.grad_target()
-            K.linear_wgrad(dy, x, g, acc)
-            wg.ready()
+            if _is_deferred(wg.params[0]):
+                _defer["items"].append((dy, x, wg))
+            else:
+                g, acc = wg.grad_target()
+                K.linear_wgrad(dy, x, g, acc)
+                wg.ready()
         dx = K.linear_dgrad(dy, wg.tensor()) if ctx.needs_input_grad[0] else None
         return dx, dres, None, None, None, None, None
 
@@ -338,6 +392,8 @@ class EmbedSpliceFn(torch.autograd.Function):
         ids, src_map, batch_idx, token_range = ctx.saved_tensors
         emb = ctx.emb
         dE = dE.contiguous()
+        if _defer is not None and _defer["items"]:      # the decoder's backward is done: release the held-back wgrads
+            _defer["event"] = flush_deferred_wgrads()
         dproj = None
         if ctx.has_proj and ctx.needs_input_grad[0]:
             dproj = torch.empty((ctx.proj_rows, dE.shape[1]), dtype=dE.dtype, device=dE.device)
