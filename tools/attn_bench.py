@@ -6,7 +6,7 @@ import torch
 from multimeditron_amd import kernels as K
 
 
-def run(B, S, Hq, Hkv, D, causal):
+def run(B, S, Hq, Hkv, D, causal, mask=False):
     W = (Hq + 2 * Hkv) * D
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = torch.randn(B * S, W, device="cuda", generator=g).to(torch.bfloat16)
@@ -15,22 +15,23 @@ def run(B, S, Hq, Hkv, D, causal):
     dq = dqkv[:, : Hq * D].view(B, S, Hq, D); dk = dqkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D); dv = dqkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
     do = torch.randn(B, S, Hq, D, device="cuda", generator=g).to(torch.bfloat16)
     sc = D ** -0.5
-    out, lse = K.attn_fwd(q, k, v, None, causal, sc)
-    K.attn_bwd(q, k, v, out, do, lse, None, causal, sc, dq, dk, dv)
+    km = torch.ones(B, S, dtype=torch.long, device="cuda") if mask else None     # all-ones key mask, as the collator sends
+    out, lse = K.attn_fwd(q, k, v, km, causal, sc)
+    K.attn_bwd(q, k, v, out, do, lse, km, causal, sc, dq, dk, dv)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     it = 5
     ev[0].record()
     for _ in range(it):
-        out, lse = K.attn_fwd(q, k, v, None, causal, sc)
+        out, lse = K.attn_fwd(q, k, v, km, causal, sc)
     ev[1].record()
     for _ in range(it):
-        K.attn_bwd(q, k, v, out, do, lse, None, causal, sc, dq, dk, dv)
+        K.attn_bwd(q, k, v, out, do, lse, km, causal, sc, dq, dk, dv)
     ev[2].record()
     torch.cuda.synchronize()
     f = 4.0 * B * Hq * S * S * D * (0.5 if causal else 1.0)
     tf, tb = ev[0].elapsed_time(ev[1]) / it, ev[1].elapsed_time(ev[2]) / it
-    print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} D={D} causal={causal}: fwd {tf:.3f} ms ({f / tf / 1e9:.0f} TF/s)  bwd {tb:.3f} ms ({2.5 * f / tb / 1e9:.0f} TF/s algorithmic)", flush=True)
+    print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} D={D} causal={causal} mask={mask}: fwd {tf:.3f} ms ({f / tf / 1e9:.0f} TF/s)  bwd {tb:.3f} ms ({2.5 * f / tb / 1e9:.0f} TF/s algorithmic)", flush=True)
 
 
 from multimeditron_amd._lib import lib
@@ -53,6 +54,8 @@ if "--ab-fwdwaves" in sys.argv:  # forward: one 8-wave workgroup per CU vs two i
 if "--quick" in sys.argv:
     run(4, 2048, 32, 8, 128, True)
     run(4, 2048, 32, 8, 128, True)
+    run(4, 2048, 32, 8, 128, True, mask=True)
+    run(4, 2048, 32, 8, 128, True, mask=True)
     sys.exit(0)
 for nw in (8, 4, 8, 4):
     lib().mm_set_option(b"attn_issue_waves", nw)
