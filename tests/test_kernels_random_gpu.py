@@ -111,3 +111,81 @@ def test_attention_random(K, case):      # noqa: F811
         assert close(dq.float(), qf.grad), case
         assert close(dk.float(), kf.grad), case
         assert close(dv.float(), vf.grad), case
+
+
+# ---- row-wise kernels on the widths the supported models use (and a few odd ones) ---------------------------------------
+def _norm_cases(n):
+    Hs = [8, 64, 136, 768, 1024, 1152, 2048, 3584, 4096, 4304, 8192]
+    return [(_rng.choice([1, 5, 16, 17, 77, 130, 1028]), _rng.choice(Hs), _rng.choice([torch.bfloat16, torch.float32]),
+             _rng.random() < 0.5) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _norm_cases(24))
+def test_norms_random(K, case):      # noqa: F811
+    M, H, dtype, with_res = case
+    x, dy = rnd((M, H), dtype, M + H), rnd((M, H), dtype, M * 3 + H)
+    w, b = (1 + 0.1 * rnd((H,), torch.float32, 7)).to(dtype), rnd((H,), dtype, 8)
+    dres = rnd((M, H), dtype, 9) if with_res else None
+    tol = TOL[dtype]
+    add = dres.float() if with_res else 0.0
+    xf, wf = x.float().clone().requires_grad_(True), w.float().clone().requires_grad_(True)
+    ref = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    ref.backward(dy.float())
+    y, rstd = K.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-6)
+    assert rel(y.float(), ref.detach()) < tol, case
+    dx, dwp = K.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstd, dres.cuda() if with_res else None)
+    dw = torch.empty(H, dtype=dtype, device="cuda")
+    K.reduce_partials(dwp, dw, False)
+    assert rel(dx.float(), xf.grad + add) < tol * 2, case
+    assert float((dw.float().cpu() - wf.grad).norm()) <= tol * 3 * float(wf.grad.norm()) + 1e-3, case
+    xf, wf, bf = (t.float().clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.layer_norm(xf, (H,), wf, bf, 1e-6)
+    ref.backward(dy.float())
+    y, mean, rstd = K.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), 1e-6)
+    assert rel(y.float(), ref.detach()) < tol, case
+    dx, dwp, dbp = K.layernorm_bwd(dy.cuda(), x.cuda(), w.cuda(), mean, rstd, dres.cuda() if with_res else None)
+    dw, db = torch.empty(H, dtype=dtype, device="cuda"), torch.empty(H, dtype=dtype, device="cuda")
+    K.reduce_partials(dwp, dw, False)
+    K.reduce_partials(dbp, db, False)
+    assert rel(dx.float(), xf.grad + add) < tol * 2, case
+    assert float((dw.float().cpu() - wf.grad).norm()) <= tol * 3 * float(wf.grad.norm()) + 1e-3, case
+    assert float((db.float().cpu() - bf.grad).norm()) <= tol * 3 * float(bf.grad.norm()) + 1e-3, case
+
+
+@pytest.mark.parametrize("case", [(_rng.choice([1, 7, 33, 130]), _rng.choice([8, 136, 4304, 8192, 14336, 18944])) for _ in range(8)])
+def test_swiglu_random(K, case):      # noqa: F811
+    M, I = case
+    dtype = torch.bfloat16
+    gu, dout = rnd((M, 2 * I), dtype, M + I), rnd((M, I), dtype, M * I % 1000)
+    guf = gu.float().clone().requires_grad_(True)
+    ref = F.silu(guf[:, :I]) * guf[:, I:]
+    ref.backward(dout.float())
+    assert rel(K.swiglu_fwd(gu.cuda(), I).float(), ref.detach()) < TOL[dtype]
+    assert rel(K.swiglu_bwd(gu.cuda(), dout.cuda(), I).float(), guf.grad) < TOL[dtype] * 2
+
+
+@pytest.mark.parametrize("case", [(_rng.choice([1, 9, 40]), _rng.choice([2, 130, 1000, 32000, 128258, 152066]), _rng.choice([torch.bfloat16, torch.float32]))
+                                  for _ in range(10)])
+def test_cross_entropy_random(K, case):      # noqa: F811
+    T, V, dtype = case
+    ld = (V + 63) // 64 * 64
+    logits = rnd((T, V), dtype, T + V, 2.0)
+    labels = torch.randint(0, V, (T,), generator=torch.Generator().manual_seed(V))
+    if T > 2:
+        labels[::3] = -100
+    lf = logits.float().clone().requires_grad_(True)
+    kept = int((labels >= 0).sum())
+    buf = torch.zeros(T, ld, dtype=dtype, device="cuda")
+    buf[:, :V] = logits.cuda()
+    lc, lse = K.ce_fwd(buf[:, :V], V, labels.cuda())
+    assert int(lc[1]) == kept
+    if kept:
+        ref = F.cross_entropy(lf, labels, ignore_index=-100)
+        ref.backward()
+        assert abs(float(lc[0]) - float(ref)) < 1e-4 * max(1, abs(float(ref))), case
+        d = torch.full_like(buf, float("nan"))
+        K.ce_bwd(buf[:, :V], V, labels.cuda(), lse, lc, None, d[:, :V])
+        assert rel(d[:, :V].float(), lf.grad) < (2e-5 if dtype == torch.float32 else 1e-2), case
+        assert torch.all(d[:, V:] == 0)
+    got = K.argmax_softmax(buf[:, :V], V, 0.1).cpu()
+    assert torch.equal(got, torch.argmax(torch.softmax(logits / 0.1, dim=-1), dim=-1)), case
