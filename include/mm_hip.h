@@ -45,8 +45,11 @@ enum {
 
 int mm_version(void);
 const char* mm_error_string(int code);
-/* tuning / A-B switches (benchmarks): "gemm_persist" 0|1, "gemm_kernel" 0 auto | 1 v1 | 2 dma256x128 | 3 dma256x256,
- * "gemm_issue_waves" 2|4|8, "attn_issue_waves" 4|8 (how many of a workgroup's 8 waves issue the LDS-DMA)           */
+/* tuning / A-B switches (benchmarks and the trainer): "gemm_persist" 0|1 (persistent one-workgroup-per-CU grid; the
+ * trainer sets 0 under data parallelism), "gemm_kernel" 0 auto | 1 register-staged 128x128 | 2..6 LDS-DMA tiles 256x128,
+ * 256x256, 128x128, 64x128, 64x64, "gemm_small" -1 auto | 0..5, "gemm_tail" 0|1 (half-tile last round), "gemm_skinny"
+ * 0|1 (M <= 16 weight-streaming kernel), "gemm_issue_waves" / "attn_issue_waves" 4|8 (how many of a workgroup's 8 waves
+ * issue the LDS-DMA), "attn_fwd_waves" 8|4, "attn_dkv_pair" 0|1.  Unknown names return MM_ERR_ARG.                  */
 int mm_set_option(const char* name, int value);
 int mm_attn_set_issue_waves(int v);
 
