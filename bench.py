@@ -3,8 +3,11 @@
 process per GPU (BASELINE.json metric; config = configs[2] "8B+ViT-L/14 bf16 full fwd+bwd (AdamW)", per-GPU micro-batch
 4 x seq 2048, 1 image/sample, FULL training mode, synthetic data, random-init weights).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps 5 --warmup 2          (N > 1: starts the N ranks itself as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus 2 --dry-run                     (CPU/gloo rehearsal of the launcher only; never a measurement)
+
+The job's rank count must equal --gpus or the run exits non-zero.
 
 Prints ONE JSON line on rank 0.  `value` = whole-job samples/s with inputs resident in HBM.  `roofline` = bf16 GEMM
 kernel (the dominant kernel: 96 % of the step's FLOPs) measured live with HIP events on the launch stream;
@@ -181,6 +184,48 @@ def cpu_baseline(llm, vis, hidden, workload, budget_layers=8, S=1024, B=2):
                        f"full workload by algorithmic FLOPs")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as CHILD processes (one per GPU,
+    `python -m torch.distributed.run`, the launch the reference documents as `torchrun --nproc-per-node N -m multimeditron
+    train`, docs/source/guides/training.rst:121,176-185) and return their exit code.  Called before anything in this
+    process has touched the GPU (a process that has initialised HIP must never exec or fork GPU children)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this host driver)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """Launcher / rendezvous rehearsal on CPU (gloo): the rank plumbing, barriers, max-over-ranks timing and the JSON line
+    of the real run with an empty step -- no model, no kernels, never a measurement (`"dry_run": true`, value 0)."""
+    import torch.distributed as dist
+    if world > 1 or "RANK" in os.environ:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if (dist.get_world_size() if dist.is_initialized() else 1) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the job has {world} rank(s)")
+    t = torch.zeros(1, dtype=torch.float64)
+    if dist.is_initialized():
+        dist.barrier()
+        t += 1.0
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)              # every rank takes part in the same collectives
+    if rank == 0:
+        print(json.dumps({"metric": "image-text samples/sec/node fwd+bwd, Llama-3.1-8B+ViT-L/14 bf16", "value": 0.0, "unit": "samples/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "ranks_seen": int(t.item()) if dist.is_initialized() else 1}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,11 +235,20 @@ def main():
     ap.add_argument("--mode", default="FULL", choices=["FULL", "ALIGNMENT", "END2END", "LM_ONLY"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal on CPU/gloo: no model, no kernels, no measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:          # bare `python bench.py --gpus N`: become the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with `python bench.py --gpus N` or "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -209,6 +263,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} rank(s)")
 
     from multimeditron_amd.model.model import MultimodalConfig, MultiModalModelForCausalLM
     from multimeditron_amd.model.modalities import ImageConfig, SiglipImageConfig
@@ -256,13 +312,15 @@ def main():
            "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "images_per_sample": n_img,
                       "training_mode": args.mode, "optimizer": "AdamW every step (fused, fp32 master+m+v)", "parallelism": f"dp{world}",
                       "final_loss": round(float(loss), 4)}}
+    # the instrumented extra step issues the same gradient-exchange collectives as any other step: EVERY rank runs it
+    # (rank 0 alone would leave its all-reduces unmatched and hang); only rank 0 reports
+    r = measure_gemm_roofline(trainer, batch) if not args.no_roofline else None
     if rank == 0:
         if fps is not None:
             step_tf = value / world * fps / 1e12
             out["config"]["flops_per_sample_fwd_bwd"] = fps
         roof = None
-        if not args.no_roofline:
-            r = measure_gemm_roofline(trainer, batch)
+        if r is not None:
             roof = {"bound": "mfma", "kernel": "gemm_bf16_dma_kernel (NT/NN/TN; every bf16 mm_gemm launch of the step)", "achieved": round(r["achieved_tflops"], 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(r["achieved_tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": r["launches"], "avg_launch_ms": round(r["avg_launch_ms"], 4),
