@@ -51,6 +51,8 @@ const char* mm_error_string(int code);
  * 0|1 (M <= 16 weight-streaming kernel), "gemm_issue_waves" / "attn_issue_waves" 4|8 (how many of a workgroup's 8 waves
  * issue the LDS-DMA), "attn_fwd_waves" 8|4, "attn_dkv_pair" 0|1.  Unknown names return MM_ERR_ARG.                  */
 int mm_set_option(const char* name, int value);
+/* current value of a "gemm_*" switch (so that a caller that flips one temporarily can restore what it found) */
+int mm_get_option(const char* name, int* value);
 int mm_attn_set_issue_waves(int v);
 
 /* ---- GEMM: every nn.Linear / Conv2d(k=s) on the path -------------------------------------

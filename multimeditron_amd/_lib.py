@@ -71,3 +71,9 @@ def call(name: str, *args):
     if rc != 0:
         msg = L.mm_error_string(rc)
         raise MMHipError(f"{name} failed: {rc} ({msg.decode() if msg else '?'})")
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int(0)
+    call("mm_get_option", name.encode(), ctypes.byref(v))
+    return v.value

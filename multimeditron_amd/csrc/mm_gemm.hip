@@ -872,6 +872,17 @@ extern "C" int mm_set_option(const char* name, int value) {
   return MM_ERR_ARG;
 }
 
+extern "C" int mm_get_option(const char* name, int* value) {
+  if (!name || !value) return MM_ERR_ARG;
+  if (!strcmp(name, "gemm_tail")) { *value = g_opt_tail; return MM_OK; }
+  if (!strcmp(name, "gemm_skinny")) { *value = g_opt_skinny; return MM_OK; }
+  if (!strcmp(name, "gemm_small")) { *value = g_opt_small; return MM_OK; }
+  if (!strcmp(name, "gemm_persist")) { *value = g_opt_persist; return MM_OK; }
+  if (!strcmp(name, "gemm_issue_waves")) { *value = g_opt_issue_waves; return MM_OK; }
+  if (!strcmp(name, "gemm_kernel")) { *value = g_opt_kernel; return MM_OK; }
+  return MM_ERR_ARG;
+}
+
 extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                        int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream) {
   if (M < 0 || N < 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;

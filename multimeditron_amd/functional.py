@@ -72,9 +72,10 @@ def flush_deferred_wgrads():
     if d is None:
         return None
     if d["items"]:
-        from ._lib import lib
+        from ._lib import get_option, lib
         main, side = torch.cuda.current_stream(), d["stream"]
         side.wait_stream(main)
+        persist = get_option("gemm_persist")         # restore what the trainer / the user had set, not a constant
         lib().mm_set_option(b"gemm_persist", 0)      # one tile per workgroup: shares the chip with the other stream's kernels
         try:
             with torch.cuda.stream(side):
@@ -87,7 +88,7 @@ def flush_deferred_wgrads():
                 ev = torch.cuda.Event()
                 ev.record(side)
         finally:
-            lib().mm_set_option(b"gemm_persist", int(d.get("persist", 1)))
+            lib().mm_set_option(b"gemm_persist", persist)
         d["items"].clear()
         d["event"] = ev
     ev, d["event"] = d["event"], None

@@ -47,6 +47,8 @@ class VisionConfig:
 
 
 class _PatchConv(nn.Module):
+    _mm_param_holder = True      # never __call__ed: VisionEmbeddings.forward reads .weight/.bias (hooks belong on the parent)
+
     def __init__(self, cfg, dtype, device):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(cfg.hidden_size, cfg.num_channels, cfg.patch_size, cfg.patch_size, dtype=dtype, device=device))
@@ -57,6 +59,8 @@ class _PatchConv(nn.Module):
 
 
 class _PosEmb(nn.Module):
+    _mm_param_holder = True
+
     def __init__(self, n, d, dtype, device):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(n, d, dtype=dtype, device=device))

@@ -36,11 +36,13 @@ class Embedding(nn.Module):
         self.num_embeddings, self.embedding_dim = num, dim
         self.weight = nn.Parameter(torch.empty(num, dim, dtype=dtype, device=device))
 
-    def forward(self, ids):
-        """Plain lookup (no splice) -> [*ids.shape, dim]."""
+    def forward(self, ids, proj=None, batch_idx=None, token_range=None):
+        """Lookup -> [*ids.shape, dim]; with `proj` [n, dim] the rows (batch_idx[i], token_range[i]) take proj[i] instead
+        (the embed-splice of reference model.py:433-444 as one gather pass).  The splice goes through the module's
+        __call__ on purpose: forward pre-hooks (the trainer's wait for this table's in-flight AdamW update) fire for it."""
         B = ids.shape[0] if ids.dim() > 1 else 1
         S = ids.numel() // B
-        out = Fm.embed_splice(self.weight, ids, None, None, None, B, S, dummy=grad_dummy(self.weight))
+        out = Fm.embed_splice(self.weight, ids, proj, batch_idx, token_range, B, S, dummy=grad_dummy(self.weight))
         return out.view(*ids.shape, self.embedding_dim)
 
 

@@ -229,20 +229,34 @@ class MultimodalTrainer:
                     runs[-1][1] = end
                 else:
                     runs.append([sg.start, end, sg.decay])
-            try:
-                mod = self.model.get_submodule(key)
-            except AttributeError:
-                mod = None
-            self._blocks.append((mod, [(a, b, d, st_off(a)) for a, b, d in runs]))
+            self._blocks.append((self._hook_module(key), [(a, b, d, st_off(a)) for a, b, d in runs]))
         covered = sum(b - a for _, rs in self._blocks for a, b, _, _ in rs)
         assert covered == sum(e - s0 for s0, e, _ in self.ranges), "optimizer pipeline must cover every trainable range"
         self._opt_stream = torch.cuda.Stream()
         self._pending: Dict[int, torch.cuda.Event] = {}
         self._all_done: Optional[torch.cuda.Event] = None
         self._hooks = []
+        self._unfired: List[int] = []
+        hooked = set()
         for mod, _ in self._blocks:
-            if mod is not None:
+            if mod is not None and id(mod) not in hooked:      # several blocks may share one call site (ViT embeddings.*)
+                hooked.add(id(mod))
                 self._hooks.append(mod.register_forward_pre_hook(self._wait_block))
+
+    def _hook_module(self, key: str):
+        """The module whose __call__ precedes every read of block `key`'s parameters in forward: the block's own module,
+        or -- for bare parameter holders that forward never calls (`_mm_param_holder`: the ViT's patch_embedding /
+        position_embedding, read by VisionEmbeddings.forward) -- the nearest ancestor that is called.  None = no such
+        call site: the update is waited for eagerly."""
+        while key:
+            try:
+                mod = self.model.get_submodule(key)
+            except AttributeError:
+                mod = None
+            if mod is not None and not getattr(mod, "_mm_param_holder", False):
+                return mod
+            key = key.rsplit(".", 1)[0] if "." in key else ""
+        return None
 
     def _wait_block(self, mod, _inputs):
         ev = self._pending.pop(id(mod), None)
@@ -252,6 +266,9 @@ class MultimodalTrainer:
     def _wait_optimizer(self):
         """Everything the side stream still owes (before gradients are overwritten or parameters read ad hoc)."""
         if getattr(self, "_all_done", None) is not None:
+            # blocks whose hook did not fire in the forward that just ran (legitimate for a tower the batch never entered;
+            # a bug if forward read them: tests/test_trainer_gpu.py checks this list is empty for an image batch)
+            self._unfired = list(self._pending)
             torch.cuda.current_stream().wait_event(self._all_done)
             self._all_done = None
             self._pending.clear()

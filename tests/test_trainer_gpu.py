@@ -53,3 +53,28 @@ def test_training_steps_match_oracle(golden_dir, tmp_path, name, mode):
         assert err < 2e-3, (k, err)
     if mode == "ALIGNMENT":   # frozen parts untouched
         assert torch.equal(params["model.model.norm.weight"].cpu().float(), w["model.model.norm.weight"].float())
+
+
+@pytest.mark.parametrize("name", ["tiny_clip_llama", "tiny_siglip_qwen2"])
+def test_optimizer_overlap_hooks_cover_every_block(golden_dir, tmp_path, name):
+    """ADVICE r1 (trainer.py:245): the side-stream AdamW of step n is guarded, block by block, by forward pre-hooks in step
+    n+1.  Every block whose parameters an image batch's forward reads must have FIRED its hook by the end of that forward
+    (embed_tokens is read by the splice, patch/position embeddings by VisionEmbeddings.forward: neither module used to be
+    __call__ed).  `_unfired` lists the blocks still pending when backward starts."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
+    try:
+        meta, w, v = R.load_golden(name, golden_dir)
+    except FileNotFoundError:
+        pytest.skip(f"fixture {name} not present")
+    model = build_from_golden(meta, w, tmp_path, "bfloat16")
+    tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=1e-3)
+    assert all(mod is not None for mod, _ in tr._blocks), "a trainable block has no call site: its update would be waited eagerly"
+    b = to_device(R.golden_batch(v, "right"))
+    tr.training_step(b)                    # launches the overlapped update
+    assert tr._pending, "the optimizer pipeline did not arm any block"
+    tr.training_step(b)                    # forward must pop every block before backward starts
+    assert tr._unfired == [], [type(m).__name__ for m, _ in tr._blocks if id(m) in tr._unfired]
+    tr.synchronize()
+    torch.cuda.synchronize()
