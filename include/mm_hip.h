@@ -73,10 +73,20 @@ int mm_splice_build_map(const int64_t* batch_idx, const int64_t* token_range, in
                         int32_t* src_map, void* stream);
 int mm_embed_splice_fwd(int dtype, const void* emb, int64_t vocab, int H, const int64_t* ids, const void* proj,
                         const int32_t* src_map, int T, void* out, void* stream);
-/* backward: dproj[i,:] = dE[pos(i),:]; demb[ids[t],:] += dE[t,:] for tokens that were NOT overwritten */
+/* token order for the embedding gradient (depends on ids / src_map only, so it is built at forward time): a stable
+ * sort of the T tokens by id; tokens overwritten by a modality row or with an id outside [0, vocab) sort last and get no
+ * gradient.  order/skey: int32 [order_elems]; key_ws: int32 [T] workspace; sizes from mm_embed_sort_sizes.            */
+int mm_embed_sort_sizes(int T, int H, int64_t* order_elems, int64_t* scratch_floats);
+int mm_embed_sort(const int64_t* ids, const int32_t* src_map, int T, int64_t vocab, int32_t* key_ws, int32_t* order,
+                  int32_t* skey, void* stream);
+/* backward (autograd of model.py:433-444): dproj[i,:] = dE[pos(i),:]; demb[id,:] (+)= sum of dE[t,:] over the tokens t
+ * with ids[t] == id that were NOT overwritten -- summed in fp32 in ascending token order, rounded once, one write per
+ * touched row: bitwise reproducible, no atomics.  accumulate = 0 overwrites the touched rows (the caller has zeroed
+ * demb), 1 adds to what demb holds (tied lm_head gradient, gradient accumulation).  scratch: fp32 [scratch_floats].   */
 int mm_embed_splice_bwd(int dtype, const void* dE, int H, const int64_t* ids, const int32_t* src_map, int T,
                         const int64_t* batch_idx, const int64_t* token_range, int n_mod, int S, void* dproj,
-                        void* demb, int64_t vocab, void* stream);
+                        void* demb, int64_t vocab, const int32_t* order, const int32_t* skey, float* scratch,
+                        int accumulate, void* stream);
 
 /* ---- ViT patch embedding glue: HF:clip:138-218 -----------------------------------------------------
  * patchify: pixels f32 [n,3,Himg,Wimg] -> patches [n*P, Kpad] (k = c*ps*ps + py*ps + px, zero padded)     */

@@ -64,32 +64,163 @@ __global__ __launch_bounds__(256) void splice_gather_bwd_kernel(const T* dE, int
   }
 }
 
-__device__ __forceinline__ void atomic_add_pair(bf16* p, float a, float b) {
-  // packed bf16 atomic add (global_atomic_pk_add_bf16); p is 4-byte aligned
-  bf16x2 v;
-  v[0] = (bf16)a;
-  v[1] = (bf16)b;
-  __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) bf16x2*)p, v);
+// ---- embedding gradient: deterministic, fp32-accumulated, one write per touched row ---------------------------------
+// backward of `embedding(input_ids)` (model.py:433): demb[id] (+)= sum over the tokens t with ids[t] == id that were not
+// overwritten by a modality row.  No float atomics (a packed-bf16 atomic rounds the running sum at every add and the
+// order of adds differs between launches).  Instead:
+//   1. mm_embed_sort (forward time: it depends only on ids and the splice map): a stable enumeration sort of the tokens
+//      by id -- pos(t) = #{t' : (key[t'], t') < (key[t], t)} -- O(T^2) integer compares from LDS, no V-sized tables, the
+//      same permutation on every launch and on every rank.  Spliced / out-of-range tokens get the key INVALID (last).
+//   2. embed_reduce_chunks_kernel: the sorted positions are cut into chunks of 32; a wave owns (chunk, 16-byte column
+//      slice), keeps its 32 gradient rows' slices in registers and walks them in ascending token order, summing each run
+//      of equal ids in fp32.  A run that lies inside the chunk is rounded once and written to demb[id]; a run that
+//      touches a chunk boundary shared with the same id goes to an fp32 scratch (two slots per chunk).
+//   3. embed_merge_partials_kernel: for every id whose run crosses chunks, the chunk where the run begins adds the
+//      partials in ascending chunk order and writes demb[id].
+// So a token id repeated thousands of times (padding) is summed by many waves, and every sum has one fixed order.
+constexpr int EMB_R = 32;                 // sorted positions per chunk
+constexpr int32_t EMB_INVALID = 0x7fffffff;
+
+__global__ void embed_key_kernel(const int64_t* ids, const int32_t* map, int Tn, int64_t vocab, int32_t* key, int32_t* skey, int Tpad) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < Tn) {
+    const int64_t id = ids[t];
+    key[t] = ((map && map[t] >= 0) || id < 0 || id >= vocab) ? EMB_INVALID : (int32_t)id;
+  } else if (t < Tpad) {
+    skey[t] = EMB_INVALID;                // padding behind the sorted keys: chunk tails read as "no token"
+  }
+}
+
+// 64 tokens per workgroup (one per lane); the 4 waves split every staged block of keys; counts are merged through LDS
+__global__ __launch_bounds__(256) void embed_rank_sort_kernel(const int32_t* key, int Tn, int32_t* order, int32_t* skey) {
+  constexpr int CH = 8192;                // keys staged per round (32 KiB)
+  __shared__ int32_t sk[CH];
+  __shared__ int cnt[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  const int32_t kt = t < Tn ? key[t] : EMB_INVALID;
+  int c = 0;
+  for (int base = 0; base < Tn; base += CH) {
+    const int n = min(CH, Tn - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < CH; i += 256) sk[i] = i < n ? key[base + i] : EMB_INVALID;
+    __syncthreads();
+    const int q = (n + 3) / 4;            // this wave's quarter [w*q, min(n, w*q+q))
+    const int j0 = w * q, j1 = min(n, j0 + q);
+    for (int j = j0; j < j1; ++j) {       // sk[j] is a broadcast read (same address in every lane)
+      const int32_t kj = sk[j];
+      c += (kj < kt) | ((kj == kt) & (base + j < t));
+    }
+  }
+  cnt[w][lane] = c;
+  __syncthreads();
+  if (w == 0 && t < Tn) {
+    const int pos = cnt[0][lane] + cnt[1][lane] + cnt[2][lane] + cnt[3][lane];
+    order[pos] = t;
+    skey[pos] = kt;
+  }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(const T* dE, int H, const int64_t* ids, const int32_t* map, int Tn,
-                                                                T* demb, int64_t vocab) {
+__device__ __forceinline__ void emb_store_row(T* dst, const float (&acc)[Vec16<T>::N], int accumulate) {
+  constexpr int VN = Vec16<T>::N;
+  Vec16<T> o;
+  if (accumulate) {
+    const Vec16<T> old = *(const Vec16<T>*)dst;
+#pragma unroll
+    for (int k = 0; k < VN; ++k) o.set(k, old.get(k) + acc[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < VN; ++k) o.set(k, acc[k]);
+  }
+  *(Vec16<T>*)dst = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_reduce_chunks_kernel(const T* dE, int H, const int32_t* order, const int32_t* skey,
+                                                                  int nchunks, int nslices, T* demb, float* part, int accumulate) {
+  constexpr int VN = Vec16<T>::N;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nw = gridDim.x * 4;
-  for (int t = wave; t < Tn; t += nw) {
-    if (map && map[t] >= 0) continue;  // overwritten by a modality row: no gradient to the embedding
-    const int64_t id = ids[t];
-    if (id < 0 || id >= vocab) continue;
-    const T* g = dE + (int64_t)t * H;
-    T* d = demb + id * H;
-    if constexpr (sizeof(T) == 4) {
-      for (int e = lane; e < H; e += 64) atomicAdd((float*)d + e, to_f32(g[e]));
+  if (wave >= nchunks * nslices) return;
+  const int c = wave / nslices, sl = wave % nslices;
+  const int col = (sl * 64 + lane) * VN;
+  const bool live = col < H;                                   // the last slice may be ragged (H % (64*VN) != 0)
+  const int p0 = c * EMB_R;
+  const int32_t myk = lane < EMB_R ? skey[p0 + lane] : EMB_INVALID;
+  const int32_t myo = lane < EMB_R ? order[p0 + lane] : 0;
+  const int32_t kfirst = __builtin_amdgcn_readfirstlane(myk);
+  if (kfirst == EMB_INVALID) return;                           // sorted: nothing valid from here on
+  const int32_t kprev = c > 0 ? skey[p0 - 1] : -1;             // -1 never equals a key
+  const int32_t knext = skey[p0 + EMB_R];                      // skey is padded by one chunk of INVALID
+  Vec16<T> rows[EMB_R];
+#pragma unroll
+  for (int i = 0; i < EMB_R; ++i) {
+    const int32_t ki = __shfl(myk, i, 64);
+    const int32_t oi = __shfl(myo, i, 64);
+    if (ki != EMB_INVALID && live) rows[i] = *(const Vec16<T>*)(dE + (int64_t)oi * H + col);
+  }
+  float acc[VN];
+#pragma unroll
+  for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+  int32_t run = kfirst;
+  bool run_at_start = true;
+  float* pc = part + ((int64_t)c * 2) * H + col;
+  auto flush = [&](int32_t rk, bool at_start, bool at_end) {
+    if (rk == EMB_INVALID || !live) return;
+    const bool ts = at_start && kprev == rk, te = at_end && knext == rk;
+    if (!ts && !te) {
+      emb_store_row<T>(demb + (int64_t)rk * H + col, acc, accumulate);
     } else {
-      for (int e = lane * 2; e < H; e += 128) atomic_add_pair((bf16*)d + e, to_f32(g[e]), to_f32(g[e + 1]));
+      float* d = pc + (ts ? 0 : (int64_t)H);                   // slot 0: run continues FROM the previous chunk; slot 1: it
+#pragma unroll                                                 // begins here and continues INTO the next one
+      for (int k = 0; k < VN; ++k) d[k] = acc[k];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < EMB_R; ++i) {
+    const int32_t ki = __shfl(myk, i, 64);
+    if (ki != run) {
+      flush(run, run_at_start, false);
+      run = ki;
+      run_at_start = false;
+#pragma unroll
+      for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+    }
+    if (ki != EMB_INVALID) {
+#pragma unroll
+      for (int k = 0; k < VN; ++k) acc[k] += rows[i].get(k);
     }
   }
+  flush(run, run_at_start, true);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_merge_partials_kernel(int H, const int32_t* skey, int nchunks, int nslices, T* demb,
+                                                                   const float* part, int accumulate) {
+  constexpr int VN = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= nchunks * nslices) return;
+  const int c = wave / nslices, sl = wave % nslices;
+  const int col = (sl * 64 + lane) * VN;
+  if (col >= H) return;
+  const int p0 = c * EMB_R;
+  const int32_t kl = skey[p0 + EMB_R - 1];                     // key of the chunk's last run
+  if (kl == EMB_INVALID || skey[p0 + EMB_R] != kl) return;     // the last run ends inside this chunk
+  if (skey[p0] == kl && c > 0 && skey[p0 - 1] == kl) return;   // the run began in an earlier chunk: that chunk leads
+  float acc[VN];
+  const float* p = part + ((int64_t)c * 2 + 1) * H + col;
+#pragma unroll
+  for (int k = 0; k < VN; ++k) acc[k] = p[k];
+  for (int cc = c + 1; cc < nchunks; ++cc) {                   // ascending chunk order: one fixed summation order
+    const float* q = part + ((int64_t)cc * 2) * H + col;
+#pragma unroll
+    for (int k = 0; k < VN; ++k) acc[k] += q[k];
+    const int q0 = cc * EMB_R;
+    if (!(skey[q0 + EMB_R - 1] == kl && skey[q0 + EMB_R] == kl)) break;   // the run ends inside chunk cc
+  }
+  emb_store_row<T>(demb + (int64_t)kl * H + col, acc, accumulate);
 }
 
 // ---- ViT glue --------------------------------------------------------------------------------------------
@@ -200,9 +331,30 @@ extern "C" int mm_embed_splice_fwd(int dtype, const void* emb, int64_t vocab, in
   return MM_OK;
 }
 
+extern "C" int mm_embed_sort_sizes(int T, int H, int64_t* order_elems, int64_t* scratch_floats) {
+  if (T < 0 || H <= 0 || !order_elems || !scratch_floats) return MM_ERR_ARG;
+  const int64_t nchunks = (T + EMB_R - 1) / EMB_R;
+  *order_elems = (nchunks + 1) * EMB_R;
+  *scratch_floats = nchunks * 2 * (int64_t)H;
+  return MM_OK;
+}
+
+extern "C" int mm_embed_sort(const int64_t* ids, const int32_t* src_map, int T, int64_t vocab, int32_t* key_ws, int32_t* order,
+                             int32_t* skey, void* stream) {
+  if (T < 0 || vocab <= 0 || (T > 0 && (!ids || !key_ws || !order || !skey))) return MM_ERR_ARG;
+  if (T == 0) return MM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int Tpad = ((T + EMB_R - 1) / EMB_R + 1) * EMB_R;
+  hipLaunchKernelGGL(embed_key_kernel, dim3((Tpad + 255) / 256), dim3(256), 0, s, ids, src_map, T, vocab, key_ws, skey, Tpad);
+  hipLaunchKernelGGL(embed_rank_sort_kernel, dim3((T + 63) / 64), dim3(256), 0, s, (const int32_t*)key_ws, T, order, skey);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
 extern "C" int mm_embed_splice_bwd(int dtype, const void* dE, int H, const int64_t* ids, const int32_t* src_map, int T,
                                    const int64_t* batch_idx, const int64_t* token_range, int n_mod, int S, void* dproj, void* demb,
-                                   int64_t vocab, void* stream) {
+                                   int64_t vocab, const int32_t* order, const int32_t* skey, float* scratch, int accumulate,
+                                   void* stream) {
   if (!dE || T < 0 || H <= 0) return MM_ERR_ARG;
   const int vn = dtype == MM_BF16 ? 8 : 4;
   if (H % vn || !mm_aligned16(dE)) return MM_ERR_ALIGN;
@@ -215,11 +367,19 @@ extern "C" int mm_embed_splice_bwd(int dtype, const void* dE, int H, const int64
       hipLaunchKernelGGL(splice_gather_bwd_kernel<float>, dim3(row_grid(n_mod)), dim3(256), 0, s, (const float*)dE, H, batch_idx, token_range, n_mod, S, T, src_map, (float*)dproj);
   }
   if (demb && T > 0) {
-    if (!ids) return MM_ERR_ARG;
-    if (dtype == MM_BF16)
-      hipLaunchKernelGGL(embed_scatter_bwd_kernel<bf16>, dim3(row_grid(T)), dim3(256), 0, s, (const bf16*)dE, H, ids, src_map, T, (bf16*)demb, vocab);
-    else
-      hipLaunchKernelGGL(embed_scatter_bwd_kernel<float>, dim3(row_grid(T)), dim3(256), 0, s, (const float*)dE, H, ids, src_map, T, (float*)demb, vocab);
+    if (!ids || !order || !skey || !scratch) return MM_ERR_ARG;      // mm_embed_sort's outputs (same ids / src_map / vocab)
+    if (!mm_aligned16(demb) || !mm_aligned16(scratch)) return MM_ERR_ALIGN;
+    (void)vocab;
+    const int nchunks = (T + EMB_R - 1) / EMB_R;
+    const int nslices = (H + 64 * vn - 1) / (64 * vn);
+    const unsigned grid = (unsigned)(((int64_t)nchunks * nslices + 3) / 4);
+    if (dtype == MM_BF16) {
+      hipLaunchKernelGGL(embed_reduce_chunks_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dE, H, order, skey, nchunks, nslices, (bf16*)demb, scratch, accumulate);
+      hipLaunchKernelGGL(embed_merge_partials_kernel<bf16>, dim3(grid), dim3(256), 0, s, H, skey, nchunks, nslices, (bf16*)demb, (const float*)scratch, accumulate);
+    } else {
+      hipLaunchKernelGGL(embed_reduce_chunks_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dE, H, order, skey, nchunks, nslices, (float*)demb, scratch, accumulate);
+      hipLaunchKernelGGL(embed_merge_partials_kernel<float>, dim3(grid), dim3(256), 0, s, H, skey, nchunks, nslices, (float*)demb, (const float*)scratch, accumulate);
+    }
   }
   MM_CHECK_LAUNCH();
   return MM_OK;

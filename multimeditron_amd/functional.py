@@ -381,16 +381,21 @@ class EmbedSpliceFn(torch.autograd.Function):
                 proj = K.cast(proj, emb.dtype)
             proj = proj.contiguous()
         out = K.embed_splice_fwd(emb.data, ids, proj, src_map)
+        order = skey = None
+        if emb.requires_grad and torch.is_grad_enabled():
+            # the embedding gradient's summation order (a stable sort of the tokens by id) depends on ids and the splice
+            # map only: built here, beside the forward, instead of at the tail of backward
+            order, skey = K.embed_sort(ids, src_map, emb.shape[0], emb.shape[1])
         ctx.emb = emb
         ctx.S = S
         ctx.has_proj = proj is not None
         ctx.proj_rows = proj.shape[0] if proj is not None else 0
-        ctx.save_for_backward(ids, src_map, batch_idx, token_range)
+        ctx.save_for_backward(ids, src_map, batch_idx, token_range, order, skey)
         return out
 
     @staticmethod
     def backward(ctx, dE):
-        ids, src_map, batch_idx, token_range = ctx.saved_tensors
+        ids, src_map, batch_idx, token_range, order, skey = ctx.saved_tensors
         emb = ctx.emb
         dE = dE.contiguous()
         if _defer is not None and _defer["items"]:      # the decoder's backward is done: release the held-back wgrads
@@ -399,11 +404,14 @@ class EmbedSpliceFn(torch.autograd.Function):
         if ctx.has_proj and ctx.needs_input_grad[0]:
             dproj = torch.empty((ctx.proj_rows, dE.shape[1]), dtype=dE.dtype, device=dE.device)
         demb = None
+        acc = False
         if emb.requires_grad:
             demb, acc = grad_target(emb)
+            if order is None:          # forward ran under no_grad bookkeeping (e.g. requires_grad flipped afterwards)
+                order, skey = K.embed_sort(ids, src_map, emb.shape[0], emb.shape[1])
             if not acc:
-                demb.zero_()
-        K.embed_splice_bwd(dE, ids, src_map, batch_idx, token_range, ctx.S, dproj, demb)
+                demb.zero_()           # rows no token touched must read 0 (the flat gradient buffer is never memset)
+        K.embed_splice_bwd(dE, ids, src_map, batch_idx, token_range, ctx.S, dproj, demb, order, skey, accumulate=acc)
         if emb.requires_grad:
             _ready(emb)
         return dproj, None, None, None, None, None, None, None

@@ -108,11 +108,28 @@ def embed_splice_fwd(emb, ids, proj, src_map):
     return out
 
 
-def embed_splice_bwd(dE, ids, src_map, batch_idx, token_range, S, dproj, demb):
+def embed_sort(ids, src_map, vocab, H):
+    """Stable token order by id for the embedding gradient -> (order, skey) int32 (padded, see mm_embed_sort_sizes)."""
+    import ctypes
+    T = ids.numel()
+    n_order, n_scr = ctypes.c_int64(0), ctypes.c_int64(0)
+    call("mm_embed_sort_sizes", T, H, ctypes.byref(n_order), ctypes.byref(n_scr))
+    order = torch.empty(n_order.value, dtype=torch.int32, device=ids.device)
+    skey = torch.empty(n_order.value, dtype=torch.int32, device=ids.device)
+    ws = torch.empty(max(T, 1), dtype=torch.int32, device=ids.device)
+    call("mm_embed_sort", _p(ids), _p(src_map), T, vocab, _p(ws), _p(order), _p(skey), _stream())
+    return order, skey
+
+
+def embed_splice_bwd(dE, ids, src_map, batch_idx, token_range, S, dproj, demb, order=None, skey=None, accumulate=False):
     T, H = dE.shape
     n = 0 if batch_idx is None else batch_idx.numel()
+    scratch = None
+    if demb is not None:
+        scratch = torch.empty(((T + 31) // 32) * 2 * H, dtype=torch.float32, device=dE.device)
     call("mm_embed_splice_bwd", dt(dE), _p(dE), H, _p(ids), _p(src_map), T, _p(batch_idx) if n else None,
-         _p(token_range) if n else None, n, S, _p(dproj), _p(demb), demb.shape[0] if demb is not None else 0, _stream())
+         _p(token_range) if n else None, n, S, _p(dproj), _p(demb), demb.shape[0] if demb is not None else 0, _p(order), _p(skey),
+         _p(scratch), int(accumulate), _stream())
 
 
 # ------------------------------------------------------------------------------------------------ ViT glue
