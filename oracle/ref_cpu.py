@@ -279,7 +279,9 @@ def multimodal_forward(w, batch, meta, stages=None):
 
 
 @torch.no_grad()
-def greedy_generate(w, batch, meta, max_new_tokens=8, temperature=0.1) -> torch.Tensor:
+def greedy_generate(w, batch, meta, max_new_tokens=8, temperature=0.1, return_logits=False) -> torch.Tensor:
+    """return_logits: also return the per-step raw logits [B, n, V] (tests use them to show that a bf16 arg-max flip is a
+    near-tie of the reference's own scores)."""
     temperature = max(temperature, 1e-6)
     llm = meta["llm"]
     eos = meta["eos_token_idx"]
@@ -289,13 +291,15 @@ def greedy_generate(w, batch, meta, max_new_tokens=8, temperature=0.1) -> torch.
     B, S = mask.shape
     cache: List = [None] * llm["num_hidden_layers"]
     finished = torch.zeros(B, dtype=torch.bool)
-    toks = []
+    toks, step_logits = [], []
     for i in range(max_new_tokens):
         if i > 0:
             pos = (S + i - 1) * torch.ones(B, 1, dtype=torch.long)
             mask = torch.cat([mask, torch.ones(B, 1, dtype=mask.dtype)], dim=-1)
         h = decoder_forward(w, nxt, mask, pos, llm, cache=cache)
-        logits = F.linear(h[:, -1, :], lm_head_weight(w, llm)) / temperature
+        raw = F.linear(h[:, -1, :], lm_head_weight(w, llm))
+        step_logits.append(raw.float())
+        logits = raw / temperature
         tok = torch.argmax(torch.softmax(logits, dim=-1), dim=-1)
         tok = torch.where(finished, torch.full_like(tok, eos), tok)
         toks.append(tok)
@@ -303,6 +307,8 @@ def greedy_generate(w, batch, meta, max_new_tokens=8, temperature=0.1) -> torch.
         if bool(finished.all()):
             break
         nxt = F.embedding(tok, w[LLM_PREFIX + "embed_tokens.weight"])[:, None, :]
+    if return_logits:
+        return torch.stack(toks, dim=1), torch.stack(step_logits, dim=1)
     return torch.stack(toks, dim=1)
 
 

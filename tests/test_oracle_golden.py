@@ -7,7 +7,7 @@ import torch
 
 from oracle import ref_cpu as R
 
-MODELS = ["tiny_clip_llama", "tiny_clip_qwen2", "tiny_siglip_qwen2"]   # the last: BASELINE config 5 plug-in (SigLIP tower)
+MODELS = ["tiny_clip_llama", "tiny_clip_qwen2", "tiny_siglip_qwen2", "tiny_clip_llama_d128"]   # tiny_siglip_qwen2: BASELINE config 5 plug-in (SigLIP tower); tiny_clip_llama_d128: the headline attention geometry (head_dim 128, GQA 4) at S up to 330, produced by the reference
 
 
 def rel(a, b):

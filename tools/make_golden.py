@@ -95,6 +95,17 @@ def llama_cfg():
                                         "original_max_position_embeddings": 8192})
 
 
+def llama_d128_cfg():
+    """The HEADLINE attention geometry at a fixture-sized width: head_dim 128, GQA 4:1, llama3 RoPE (Llama-3.1-8B runs
+    32/8 heads x 128).  hidden stays 128, so q_proj is 128 -> 512 (HF allows head_dim * heads != hidden)."""
+    return LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                       num_key_value_heads=1, head_dim=128, vocab_size=128, rms_norm_eps=1e-5,
+                       max_position_embeddings=131072, tie_word_embeddings=False,
+                       rope_parameters={"rope_type": "llama3", "rope_theta": 500000.0, "factor": 8.0,
+                                        "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                        "original_max_position_embeddings": 8192})
+
+
 def qwen2_cfg():
     return Qwen2Config(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
                        num_key_value_heads=1, vocab_size=128, rms_norm_eps=1e-6, max_position_embeddings=32768,
@@ -241,14 +252,19 @@ def run_case(model, batch, tag, out, do_grads=True, do_generate=False):
             out[f"{tag}.greedy_T{T}"] = ids.clone()
 
 
-def model_fixture(name, llm_cfg, seed):
+def model_fixture(name, llm_cfg, seed, long_seq=False):
     with tempfile.TemporaryDirectory() as tmp:
         model = build_model(llm_cfg, seed, tmp)
         out = {}
-        run_case(model, make_batch(seed + 1, 48, [[3], [2, 24]], "right"), "right", out)
-        run_case(model, make_batch(seed + 2, 48, [[4], [2, 22]], "left"), "left", out, do_grads=False, do_generate=True)
-        run_case(model, make_batch(seed + 3, 40, [[], []], "none"), "textonly", out, do_grads=False, do_generate=True)
-        run_case(model, make_batch(seed + 4, 80, [[2, 21, 40, 60]], "none"), "interleaved4", out, do_grads=False)
+        if long_seq:    # sequences that cross the D = 128 kernels' 64-key tiles and 256-row query blocks
+            run_case(model, make_batch(seed + 1, 300, [[3], [2, 150]], "right"), "right", out)
+            run_case(model, make_batch(seed + 2, 200, [[4], [2, 122]], "left"), "left", out, do_grads=False, do_generate=True)
+            run_case(model, make_batch(seed + 4, 330, [[2, 81, 160, 260]], "none"), "interleaved4", out, do_grads=False)
+        else:
+            run_case(model, make_batch(seed + 1, 48, [[3], [2, 24]], "right"), "right", out)
+            run_case(model, make_batch(seed + 2, 48, [[4], [2, 22]], "left"), "left", out, do_grads=False, do_generate=True)
+            run_case(model, make_batch(seed + 3, 40, [[], []], "none"), "textonly", out, do_grads=False, do_generate=True)
+            run_case(model, make_batch(seed + 4, 80, [[2, 21, 40, 60]], "none"), "interleaved4", out, do_grads=False)
         # weights (only what the hot path uses: vision tower, projector, LLM)
         w = {}
         for n, p in model.state_dict().items():
@@ -543,11 +559,13 @@ def collator_fixture():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["llama", "qwen2", "siglip", "collator"]
+    which = sys.argv[1:] or ["llama", "qwen2", "llama_d128", "siglip", "collator"]
     if "llama" in which:
         model_fixture("tiny_clip_llama", llama_cfg(), 100)
     if "qwen2" in which:
         model_fixture("tiny_clip_qwen2", qwen2_cfg(), 200)
+    if "llama_d128" in which:
+        model_fixture("tiny_clip_llama_d128", llama_d128_cfg(), 400, long_seq=True)
     if "siglip" in which:
         siglip_fixture()
     if "collator" in which:
