@@ -217,29 +217,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
   }
 }
 
-// out[h] (+)= sum_b partial[b][h]: 64 columns x 4 row lanes per block, 4 independent loads in flight per thread
+// out[h] (+)= sum_b partial[b][h].  16 columns per workgroup (H/16 workgroups: 256 for H = 4096, one per CU) x 64 row
+// lanes, every lane's 16-byte loads of its rows all in flight at once, then a fixed-order tree through LDS (deterministic).
+// The old shape (64 columns x 4 row lanes, 64 workgroups, 4-byte loads: 128 dependent rounds per thread) took 44 us on the
+// decoder's 512 x 4096 partials (8.4 MB, L2/MALL resident); this one is bounded by one round of L2 latency.
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* p, int nblk, int H, T* out, int accumulate) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int h = blockIdx.x * 64 + c;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (h < H) {
+  __shared__ f32x4 red[64][4];
+  const int c4 = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int h = blockIdx.x * 16 + c4 * 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (h < H) {                      // H % 4 == 0 (checked by the host entry)
     int b = rl;
-    for (; b + 12 < nblk; b += 16) {
-      s0 += p[(int64_t)b * H + h];
-      s1 += p[(int64_t)(b + 4) * H + h];
-      s2 += p[(int64_t)(b + 8) * H + h];
-      s3 += p[(int64_t)(b + 12) * H + h];
+    for (; b + 192 < nblk; b += 256) {
+      const f32x4 v0 = *(const f32x4*)(p + (int64_t)b * H + h);
+      const f32x4 v1 = *(const f32x4*)(p + (int64_t)(b + 64) * H + h);
+      const f32x4 v2 = *(const f32x4*)(p + (int64_t)(b + 128) * H + h);
+      const f32x4 v3 = *(const f32x4*)(p + (int64_t)(b + 192) * H + h);
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
-    for (; b < nblk; b += 4) s0 += p[(int64_t)b * H + h];
+    for (; b < nblk; b += 64) s0 += *(const f32x4*)(p + (int64_t)b * H + h);
   }
-  red[rl][c] = (s0 + s1) + (s2 + s3);
+  red[rl][c4] = (s0 + s1) + (s2 + s3);
   __syncthreads();
+#pragma unroll
+  for (int st = 32; st > 0; st >>= 1) {
+    if (rl < st) red[rl][c4] += red[rl + st][c4];
+    __syncthreads();
+  }
   if (rl == 0 && h < H) {
-    float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    if (accumulate) t += to_f32(out[h]);
-    out[h] = from_f32<T>(t);
+    const f32x4 t = red[0][c4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = t[i];
+      if (accumulate) v += to_f32(out[h + i]);
+      out[h + i] = from_f32<T>(v);
+    }
   }
 }
 
@@ -629,8 +642,9 @@ extern "C" int mm_layernorm_bwd(int dtype, const void* dy, const void* x, const 
 
 extern "C" int mm_reduce_partials(int dtype, const float* partial, int nblk, int H, void* out, int accumulate, void* stream) {
   if (!partial || !out || nblk < 0 || H <= 0) return MM_ERR_ARG;
+  if ((H & 3) || !mm_aligned16(partial)) return MM_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((H + 63) / 64), block(256);
+  dim3 grid((H + 15) / 16), block(256);
   if (dtype == MM_BF16)
     hipLaunchKernelGGL(reduce_partials_kernel<bf16>, grid, block, 0, s, partial, nblk, H, (bf16*)out, accumulate);
   else

@@ -379,6 +379,18 @@ def gradnorm(flat_grads, max_norm):
     return total
 
 
+def gradnorm_partial(g, partial):
+    """sum of squares of one flat gradient slice -> partial[:] (one float per workgroup; any stream)."""
+    call("mm_gradnorm_partial", dt(g), _p(g), g.numel(), _p(partial), partial.numel(), _stream())
+
+
+def gradnorm_finish(partial, max_norm):
+    """-> device tensor [2] = (total_norm, clip_coef) from all the partial slots, summed in slot order (deterministic)."""
+    total = torch.empty(2, dtype=torch.float32, device=partial.device)
+    call("mm_gradnorm_finish", _p(partial), partial.numel(), float(max_norm), _p(total), _stream())
+    return total
+
+
 def adamw_step(p, g, master, m, v, lr, beta1, beta2, eps, wd, step, clip=None):
     call("mm_adamw_step", dt(p), _p(p), _p(g), _p(master), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
          float(eps), float(wd), int(step), _p(clip), _stream())

@@ -275,6 +275,10 @@ class CausalLM(nn.Module):
             position_ids = (torch.arange(S, device=dev) + past).unsqueeze(0).expand(B, S)
         cos, sin = self._tables(position_ids.to(dev))
         key_mask = None
+        if attention_mask is not None and past == 0 and (
+                getattr(attention_mask, "_mm_all_ones", False) or (not attention_mask.is_cuda and bool(attention_mask.all()))):
+            attention_mask = None       # an all-ones mask masks nothing (HF: _ignore_causal_mask_sdpa).  Known without a device
+                                        # sync only for a host tensor, or from the flag DevicePrefetcher computed on the host copy
         if attention_mask is not None:
             key_mask = attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         x = inputs_embeds.reshape(B * S, H)

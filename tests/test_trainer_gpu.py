@@ -78,3 +78,33 @@ def test_optimizer_overlap_hooks_cover_every_block(golden_dir, tmp_path, name):
     assert tr._unfired == [], [type(m).__name__ for m, _ in tr._blocks if id(m) in tr._unfired]
     tr.synchronize()
     torch.cuda.synchronize()
+
+
+def test_early_gradnorm_chunks_equal_full_norm(golden_dir, tmp_path, monkeypatch):
+    """The global grad norm is assembled from per-layer sums of squares taken on a side stream DURING backward (layers whose
+    wgrads are final) plus the late remainder.  It must equal the norm of the complete flat gradient, and be identical
+    run to run (fixed partial slots, fixed summation order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    monkeypatch.setenv("MM_DEFER_WGRAD_LAYERS", "1")          # layer 0 deferred (late chunk), layer 1 early
+    from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
+    meta, w, v = R.load_golden("tiny_clip_llama", golden_dir)
+    norms = []
+    for rep in range(2):
+        model = build_from_golden(meta, w, tmp_path / f"m{rep}", "bfloat16")
+        tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=0.0, weight_decay=0.0, max_grad_norm=1.0)
+        assert tr._norm_triggers, "no early chunk was set up"
+        assert len(tr._norm_chunks) > len(tr._norm_triggers)
+        covered = sorted((s, e) for s, e, _ in tr._norm_chunks)
+        assert sum(e - s for s, e in covered) == sum(e - s for s, e, _ in tr.ranges)
+        assert all(a[1] <= b[0] for a, b in zip(covered[:-1], covered[1:])), "chunks overlap"
+        tr.training_step(to_device(R.golden_batch(v, "right")))
+        assert set(tr._norm_triggers.values()) <= tr._norm_done
+        tr.synchronize()
+        torch.cuda.synchronize()
+        g = tr.flat.grad
+        ref = torch.sqrt(sum((g[s:e].double() ** 2).sum() for s, e, _ in tr.ranges))
+        got = tr.last_grad_norm[0].double()
+        assert abs(float(got) - float(ref)) < 1e-5 * float(ref), (float(got), float(ref))
+        norms.append(tr.last_grad_norm.clone())
+    assert torch.equal(norms[0], norms[1])

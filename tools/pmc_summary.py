@@ -47,7 +47,10 @@ for k, v in agg.items():
     wb += v.get("WRITE_SIZE", 0.0) * 1024.0
     wl += calls[(k, "WRITE_SIZE")]
 if fl and wl and len(sys.argv) > 2:
-    json.dump({"kernel": "gemm_bf16_dma_kernel (all instantiations)", "read_bytes_per_launch": fb / fl, "write_bytes_per_launch": wb / wl,
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import kernel_source_sha
+    json.dump({"kernel_source_sha": kernel_source_sha(), "kernel": "gemm_bf16_dma_kernel (all instantiations)", "read_bytes_per_launch": fb / fl, "write_bytes_per_launch": wb / wl,
                "bytes_per_launch": fb / fl + wb / wl, "launches_counted": int(fl),
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 1 "
                          "--no-cpu-baseline --no-roofline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 correction); KiB -> bytes"},
