@@ -100,12 +100,34 @@ def measure_gemm_roofline(trainer, batch):
         rec.append((e0, e1, 2.0 * M * N * Kd, (layout, M, N, Kd)))
         return out
 
-    K.gemm = timed
+    orig_sf, orig_sb = K.gemm_swiglu_fwd, K.gemm_swiglu_bwd
+
+    def timed_sf(x2d, wgu, I):                       # the fused gate|up GEMM (+SwiGLU epilogue): M x 2I x K
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_sf(x2d, wgu, I)
+        e1.record()
+        if out is not None:
+            M, Kd = x2d.shape
+            rec.append((e0, e1, 2.0 * M * 2 * I * Kd, ("NT+swiglu", M, 2 * I, Kd)))
+        return out
+
+    def timed_sb(dy2d, wd, gu, I):                   # down_proj dgrad (+SwiGLU backward epilogue): M x I x H
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_sb(dy2d, wd, gu, I)
+        e1.record()
+        if out is not None:
+            M, H = dy2d.shape
+            rec.append((e0, e1, 2.0 * M * I * H, ("NN+swiglu_bwd", M, I, H)))
+        return out
+
+    K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd = timed, timed_sf, timed_sb
     try:
         trainer.training_step(batch)
         torch.cuda.synchronize()
     finally:
-        K.gemm = orig
+        K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd = orig, orig_sf, orig_sb
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
     tot_fl = sum(f for _, _, f, _ in rec)
     alg_bytes = sum(2.0 * (M * Kd + N * Kd + M * N) for _, _, _, (_, M, N, Kd) in rec)      # A, B, C once, bf16

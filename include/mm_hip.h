@@ -63,6 +63,17 @@ int mm_attn_set_issue_waves(int v);
 int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream);
 
+/* SwiGLU MLP front half in ONE GEMM: replaces `act_fn(gate_proj(x)) * up_proj(x)` (HF:llama:163-176) = two F.linear + silu +
+ * mul.  Wgu = the fused [2I, K] gate|up weight (gate rows first); GU [M, 2I] receives the bf16 pre-activations (what the two
+ * linears would store; kept for backward), ACT [M, I] = bf16(bf16(silu(gate)) * up): bit-identical to mm_gemm + mm_swiglu_fwd.
+ * bf16 only; MM_ERR_UNSUPPORTED when I % 128, K % 64 or M < 256 (use the two-launch form then).                              */
+int mm_gemm_swiglu_fwd(int dtype, int M, int I, int K, const void* X, int ldx, const void* Wgu, int ldw, void* GU, int ldgu,
+                       void* ACT, int ldact, void* stream);
+/* backward of down_proj's input and of the SwiGLU in one launch: dGU [M, 2I] = swiglu'(GU) * (dY [M, H] . Wd [H, I]), the
+ * product d(act) staying in registers (autograd of HF:llama:163-176; bit-identical to mm_gemm NN + mm_swiglu_bwd).          */
+int mm_gemm_swiglu_bwd(int dtype, int M, int I, int H, const void* dY, int lddy, const void* Wd, int ldw, const void* GU,
+                       int ldgu, void* dGU, int lddgu, void* stream);
+
 /* column sums: out[N] (+)= sum_m X[m,n]   (bias gradients)                                           */
 int mm_colsum(int dtype, const void* X, int M, int N, int ldx, void* out, int accumulate, void* stream);
 

@@ -705,6 +705,35 @@ __device__ __forceinline__ SRsrc rows_rsrc(const bf16* base, int nrows, int64_t 
   return make_srsrc(base, nrows > 0 ? ((int64_t)(nrows - 1) * stride + 128) * 2 : 0);
 }
 
+// single-instruction VALU helpers for the softmax of the D = 128 kernels (rocprofv3: the forward issued 10.8 VALU
+// instructions per MFMA and was VALU-issue bound).  A plain fmaxf on MFMA results gets a canonicalising v_max in front of it
+// (48 v_max + 8 v_max3 for a 32-value row maximum); __shfl_xor(.., 32) is a ds_bpermute round trip through the LDS.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max / sum of x with its partner lane (l ^ 32): one v_permlane32_swap
+__device__ __forceinline__ float swap32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return vmax3(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float swap32_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// maximum of the 32 scores a lane holds for its query row (two 32x32 accumulator tiles)
+__device__ __forceinline__ float rowmax32(const f32x16& a, const f32x16& b) {
+  float m0 = vmax3(a[0], a[1], a[2]), m1 = vmax3(b[0], b[1], b[2]);
+#pragma unroll
+  for (int r = 3; r < 15; r += 2) { m0 = vmax3(m0, a[r], a[r + 1]); m1 = vmax3(m1, b[r], b[r + 1]); }
+  return vmax3(m0, m1, vmax3(a[15], b[15], b[15]));
+}
+// (A LAZY rescale -- guide T13: bring O and l to a new running maximum only when some row's maximum grew by more than a
+// threshold, a wave-uniform branch -- was built and measured: no gain on this kernel (686 vs 676-689 TF/s: it is not VALU
+// bound) and it costs the bit-exact causality / padding invariance of the forward, because the
+// decision is taken per WAVE and so depends on the other 31 rows of the wave.  Not used.)
+
 // Work order of the D = 128 kernels (1-D grid).  Under a causal mask a block's work grows with its position, and the
 // hardware hands out workgroups in index order: with the heaviest blocks LAST the launch ends on a few long workgroups
 // (62 vs 40 tile-times for 8 blocks x 128 heads on 512 slots).  Heaviest first fixes that.  Workgroup ids that are
@@ -763,10 +792,26 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_fwd128_kernel(AttnArgs a) {
     const int qmax = min(a.Sq - 1, qblk * QB + QB - 1) + shift;
     ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
   }
+  // per-lane source offsets of this wave's DMA pieces, computed ONCE (they were recomputed for every tile: 176 VALU
+  // instructions per issuing wave and tile); a tile only adds its wave-uniform row offset
+  constexpr int PPW = BKV / (4 * INW);
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  unsigned kofs[PPW], vofs[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int row = (wu * PPW + i) * 4 + (l >> 4);
+    const int ch = (l & 15) ^ imgb_swz(row);
+    kofs[i] = (unsigned)((int64_t)row * a.k_ss * 2 + ch * 16);
+    vofs[i] = (unsigned)((int64_t)row * a.v_ss * 2 + ch * 16);
+  }
   auto issue = [&](int t) {
-    const unsigned st = lds0 + (unsigned)((t & 1) * 2 * TILE);
-    imgb_dma<BKV, INW, NWV>(st, rk, a.k_ss, t * BKV);
-    imgb_dma<BKV, INW, NWV>(st + TILE, rv, a.v_ss, t * BKV);
+    if (wu >= INW) return;                    // only the first INW waves issue (staggers the two waves of every SIMD)
+    const unsigned st = lds0 + (unsigned)((t & 1) * 2 * TILE) + (unsigned)(wu * PPW) * 1024u;
+    const unsigned tk = (unsigned)((int64_t)t * BKV * a.k_ss * 2), tv = (unsigned)((int64_t)t * BKV * a.v_ss * 2);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) lds_dma16(rk, kofs[i] + tk, st + i * 1024);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) lds_dma16(rv, vofs[i] + tv, st + TILE + i * 1024);
   };
   if (ntiles > 0) issue(0);
   for (int t = 0; t < ntiles; ++t) {
@@ -818,17 +863,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_fwd128_kernel(AttnArgs a) {
           const int kl = kb * 32 + acc_row(r, h);
           bool ok = (kbits >> kl) & 1ull;
           if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
-          const float tv = ok ? s_acc[kb][r] : -INFINITY;
-          s_acc[kb][r] = tv;
-          mx = fmaxf(mx, tv);
+          s_acc[kb][r] = ok ? s_acc[kb][r] : -INFINITY;
         }
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s_acc[kb][r], s_acc[kb][r + 1]));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+    mx = swap32_max(rowmax32(s_acc[0], s_acc[1])) * sc;
     const float m_new = fmaxf(m_run, mx);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
@@ -863,7 +901,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_fwd128_kernel(AttnArgs a) {
     }
 #endif
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = swap32_sum(l_run);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (qi < a.Sq) {
     bf16* orow = (bf16*)a.out + (((int64_t)b * a.Sq + qi) * a.Hq + hq) * 128;

@@ -37,7 +37,14 @@ struct GemmArgs {
   int epi;
   int nbm, nbn;
   int tail;   // persistent 256x256 grid only: the last `tail` tiles are each cut into two 256x128 halves (see the kernel)
+  // fused SwiGLU (mm_gemm_swiglu_fwd): swi_I = intermediate size I (0 = plain GEMM).  B is the fused [2I, K] gate|up weight;
+  // a 256-column tile holds 128 gate columns and the 128 matching up columns, interleaved per wave so that a lane owns both
+  // values of a feature; C = pre-activations [M, 2I] (kept for backward), C2 = silu(gate) * up [M, I].
+  int swi_I;
+  void* C2; int ldc2;
+  const void* aux; int ldaux;   // MM_EPI_SWIGLU_BWD: the saved pre-activations [M, 2I]
 };
+constexpr int MM_EPI_SWIGLU_BWD = 1 << 20;   // internal epilogue flag (mm_gemm_swiglu_bwd), not part of the ABI enum
 
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
@@ -165,6 +172,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
       if (n >= g.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       const bool full = (n + 3) < g.N;
+      if (epi & MM_EPI_SWIGLU_BWD) {
+        // C = d(gate|up) [M, 2N]; acc = d(act) [M, N] (down_proj's input gradient); aux = saved gate|up.  Same arithmetic and
+        // rounding points as down_proj dgrad (bf16 store) followed by swiglu_bwd_kernel: N % 4 == 0 is checked by the host.
+        const bf16* gp = (const bf16*)g.aux + (int64_t)m * g.ldaux + n;
+        const bf16x4 gv = *(const bf16x4*)gp, uv = *(const bf16x4*)(gp + g.N);
+        bf16x4 dg, du;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gf = (float)gv[r], sig = 1.0f / (1.0f + __expf(-gf));
+          const float sg = gf * sig;
+          const float dd = (float)(bf16)v[r];
+          du[r] = (bf16)(dd * sg);
+          dg[r] = (bf16)(dd * (float)uv[r] * (sig * (1.0f + gf * (1.0f - sig))));
+        }
+        bf16* dp = C + (int64_t)m * g.ldc + n;
+        *(bf16x4*)dp = dg;
+        *(bf16x4*)(dp + g.N) = du;
+        continue;
+      }
       bf16* cp = C + (int64_t)m * g.ldc + n;
       if (epi & MM_EPI_BIAS) {
 #pragma unroll
@@ -281,6 +307,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------------
 constexpr int G_BK = 64;
 
+// epilogue of the fused gate|up GEMM: acc[i][j] (j < NREP/2) = gate of features fw + j*16 + 4*(l>>4) + r, acc[i][j + NREP/2] = up
+// of the SAME features (the B tile's rows were gathered that way).  Writes the bf16 pre-activations (what the unfused GEMM
+// stores) and act = silu(gate) * up computed from those rounded values exactly as swiglu_fwd_kernel does: bit-identical
+// to GEMM + mm_swiglu_fwd, one pass less over [M, 2I] and one launch less per layer.
+template <int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int fw) {
+  const int l = threadIdx.x & 63;
+  bf16* GU = (bf16*)g.C;
+  bf16* ACT = (bf16*)g.C2;
+  const int I = g.swi_I;
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    const int m = mw + i * 16 + (l & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < NREP / 2; ++j) {
+      const int f = fw + j * 16 + 4 * (l >> 4);
+      if (f >= I) continue;                       // I % 4 == 0
+      bf16x4 gb, ub, o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { gb[r] = (bf16)acc[i][j][r]; ub[r] = (bf16)acc[i][j + NREP / 2][r]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gf = (float)gb[r];
+        const float sg = (float)(bf16)(gf / (1.0f + __expf(-gf)));     // HF: act_fn(gate) in the storage dtype, then multiply
+        o[r] = (bf16)(sg * (float)ub[r]);
+      }
+      bf16* gp = GU + (int64_t)m * g.ldc + f;
+      *(bf16x4*)gp = gb;
+      *(bf16x4*)(gp + I) = ub;
+      *(bf16x4*)(ACT + (int64_t)m * g.ldc2 + f) = o;
+    }
+  }
+}
+
 // N LDS-DMA pieces of one operand tile in ONE asm statement: M0 saved/restored once, one hazard pad for the
 // freshly written descriptor SGPRs (the compiler pads nothing inside an asm string).
 template <int N, int STEP>
@@ -329,9 +390,15 @@ __device__ __forceinline__ SRsrc tile_rsrc(const bf16* base, int ld, int x0, int
   else return make_srsrc(base + x0, ((int64_t)Ktot * ld - x0) * 2);
 }
 
+// fused SwiGLU: local row r of the 256-row B tile (wave wn = r >> 6 owns 64 of them as 4 n-tiles of 16: two gate, two up)
+// -> row of the fused [2I, K] weight relative to the tile's first gate row
+__device__ __forceinline__ int swiglu_row(int r, int I) {
+  return (r >> 6) * 32 + ((r >> 4) & 1) * 16 + (r & 15) + ((r >> 5) & 1) * I;
+}
+
 // NW = number of waves that issue the tile's DMA (8 = all; 4 = waves 0-3 only, which staggers the two waves of a SIMD)
 template <bool KC, int XR, int NW>
-__device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld, int k0, int Ktot) {
+__device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld, int k0, int Ktot, int swi_I = 0) {
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int PPW = XR / (8 * NW);      // 1-KiB pieces per issuing wave
@@ -346,7 +413,8 @@ __device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld,
       if constexpr (KC) {                 // piece = 8 rows x 128 B
         const int row = pc * 8 + (l >> 3);
         const int kc = (l & 7) ^ kc_swz(row);           // source chunk whose home is slot (l&7) of this row
-        unsigned off = (unsigned)(row * ld + k0 + kc * 8) * 2u;
+        const int srow = swi_I ? swiglu_row(row, swi_I) : row;
+        unsigned off = (unsigned)(srow * ld + k0 + kc * 8) * 2u;
         if ((k0 + kc * 8) >= Ktot) off = 0xFFFFFFFFu;
         offs[i] = off;
       } else {
@@ -368,7 +436,7 @@ __device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld,
 // of the hardware range check, so this form is only used for K-steps that lie wholly inside K (the ragged last step
 // goes through dma_tile, whose offsets carry the K bound).
 template <bool KC, int XR, int NW>
-__device__ __forceinline__ void dma_offsets(unsigned (&offs)[XR / (8 * NW)], int ld) {
+__device__ __forceinline__ void dma_offsets(unsigned (&offs)[XR / (8 * NW)], int ld, int swi_I = 0) {
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int PPW = XR / (8 * NW);
@@ -378,7 +446,7 @@ __device__ __forceinline__ void dma_offsets(unsigned (&offs)[XR / (8 * NW)], int
     if constexpr (KC) {
       const int row = pc * 8 + (l >> 3);
       const int kc = (l & 7) ^ kc_swz(row);
-      offs[i] = (unsigned)(row * ld + kc * 8) * 2u;
+      offs[i] = (unsigned)((swi_I ? swiglu_row(row, swi_I) : row) * ld + kc * 8) * 2u;
     } else {
       constexpr int SPR = XR / 8, RPP = 64 / SPR;
       const int k = pc * RPP + l / SPR;
@@ -472,14 +540,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   int tile = blockIdx.x;
   int pm = 0, pn = 0;
   if (tile < total_full) block_to_tile(tile, g.nbm, g.nbn, pm, pn);
-  int m0 = pm * BM_, n0 = pn * BN_;
+  const int swi = (B_KC && BN_ == 256 && WGM == 2) ? g.swi_I : 0;       // fused SwiGLU: a tile = 128 features (gate + up)
+  const int nstep = swi ? BN_ / 2 : BN_;
+  int m0 = pm * BM_, n0 = pn * nstep;
   SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
   SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
   constexpr bool INV = (BM_ / (8 * ISSUE_WAVES)) % 4 == 0 && (BN_ / (8 * ISSUE_WAVES)) % 4 == 0;
   unsigned offa[INV ? BM_ / (8 * ISSUE_WAVES) : 1], offb[INV ? BN_ / (8 * ISSUE_WAVES) : 1];
   if constexpr (INV) {
     dma_offsets<A_KC, BM_, ISSUE_WAVES>(offa, g.lda);
-    dma_offsets<B_KC, BN_, ISSUE_WAVES>(offb, g.ldb);
+    dma_offsets<B_KC, BN_, ISSUE_WAVES>(offb, g.ldb, swi);
   }
   const int nk_full = g.K / G_BK;                                     // K-steps wholly inside K
   const unsigned sa = A_KC ? (unsigned)(G_BK * 2) : (unsigned)(G_BK * 2) * (unsigned)g.lda;   // soffset per K-step
@@ -494,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
       }
     }
     dma_tile<A_KC, BM_, ISSUE_WAVES>(st, da, g.lda, t * G_BK, g.K);
-    dma_tile<B_KC, BN_, ISSUE_WAVES>(st + A_BYTES, db, g.ldb, t * G_BK, g.K);
+    dma_tile<B_KC, BN_, ISSUE_WAVES>(st + A_BYTES, db, g.ldb, t * G_BK, g.K, swi);
   };
   static_assert(STAGES == 2, "the persistent stream below is written for the 2-stage ring");
   int sidx = 0;                                                       // global K-step counter (ring position)
@@ -512,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
       int qm, qn;
       block_to_tile(next, g.nbm, g.nbn, qm, qn);
       nm0 = qm * BM_;
-      nn0 = qn * BN_;
+      nn0 = qn * nstep;
       nra = tile_rsrc<A_KC>(A, g.lda, nm0, g.M, g.K);
       nrb = tile_rsrc<B_KC>(B, g.ldb, nn0, g.N, g.K);
     }
@@ -564,7 +634,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
         }
       }
     }
-    gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    if (swi) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
+    else gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     tile = next;
     m0 = nm0;
     n0 = nn0;
@@ -883,6 +954,8 @@ extern "C" int mm_get_option(const char* name, int* value) {
   return MM_ERR_ARG;
 }
 
+static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s);
+
 extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                        int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream) {
   if (M < 0 || N < 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;
@@ -890,8 +963,42 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
   if (!A || !B || !C) return MM_ERR_ARG;
   if ((epilogue & MM_EPI_BIAS) && !bias) return MM_ERR_ARG;
   if ((epilogue & MM_EPI_RESIDUAL) && !residual) return MM_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, 0, 0, 0};
+  if (epilogue & ~63) return MM_ERR_ARG;
+  GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, 0, 0, 0, 0, nullptr, 0, nullptr, 0};
+  return gemm_launch(g, dtype, layout, (hipStream_t)stream);
+}
+
+// y = silu(x Wg^T) * (x Wu^T) with ONE GEMM over the fused [2I, K] gate|up weight (HF:models/llama/modeling_llama.py:163-176
+// `act_fn(gate_proj(x)) * up_proj(x)`): GU [M, 2I] receives the pre-activations (saved for backward), ACT [M, I] the product.
+// MM_ERR_UNSUPPORTED when the shape does not take the 256x256 LDS-DMA tile (the caller then uses mm_gemm + mm_swiglu_fwd).
+extern "C" int mm_gemm_swiglu_fwd(int dtype, int M, int I, int K, const void* X, int ldx, const void* Wgu, int ldw, void* GU, int ldgu,
+                                  void* ACT, int ldact, void* stream) {
+  if (M < 0 || I <= 0 || K <= 0) return MM_ERR_ARG;
+  if (M == 0) return MM_OK;
+  if (!X || !Wgu || !GU || !ACT) return MM_ERR_ARG;
+  if (dtype != MM_BF16 || (I & 127) || (K & 63) || M < 256) return MM_ERR_UNSUPPORTED;
+  if ((ldgu & 3) || (ldact & 3) || (((uintptr_t)ACT) & 7) || (int64_t)2 * I * ldw * 2 >= 0xFFFFFFFFll) return MM_ERR_ALIGN;
+  GemmArgs g{M, 2 * I, K, X, ldx, Wgu, ldw, GU, ldgu, nullptr, nullptr, 0, 0, 0, 0, 0, I, ACT, ldact, nullptr, 0};
+  return gemm_launch(g, dtype, MM_GEMM_NT, (hipStream_t)stream);
+}
+
+// d(gate|up) [M, 2I] = swiglu'(GU) applied to d(act) = dY [M, H] . Wd [H, I], in the dgrad GEMM's epilogue: the backward of
+// down_proj's input and of the SwiGLU in one launch (d(act) never goes to HBM).  Any GEMM variant (epilogue only).
+extern "C" int mm_gemm_swiglu_bwd(int dtype, int M, int I, int H, const void* dY, int lddy, const void* Wd, int ldw, const void* GU,
+                                  int ldgu, void* dGU, int lddgu, void* stream) {
+  if (M < 0 || I <= 0 || H <= 0) return MM_ERR_ARG;
+  if (M == 0) return MM_OK;
+  if (!dY || !Wd || !GU || !dGU) return MM_ERR_ARG;
+  if (dtype != MM_BF16 || (I & 3)) return MM_ERR_UNSUPPORTED;
+  if ((ldgu & 3) || (lddgu & 3) || (((uintptr_t)GU) & 7) || (((uintptr_t)dGU) & 7)) return MM_ERR_ALIGN;
+  GemmArgs g{M, I, H, dY, lddy, Wd, ldw, dGU, lddgu, nullptr, nullptr, 0, MM_EPI_SWIGLU_BWD, 0, 0, 0, 0, nullptr, 0, GU, ldgu};
+  return gemm_launch(g, dtype, MM_GEMM_NN, (hipStream_t)stream);
+}
+
+static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
+  const int M = g.M, N = g.N, K = g.K, lda = g.lda, ldb = g.ldb, ldc = g.ldc, ldr = g.ldr, epilogue = g.epi;
+  const void *A = g.A, *B = g.B;
+  void* C = g.C;
   if (dtype == MM_BF16) {
     if ((lda & 7) || (ldb & 7) || (ldc & 3) || ((epilogue & MM_EPI_RESIDUAL) && (ldr & 3))) return MM_ERR_ALIGN;
     if (!mm_aligned16(A) || !mm_aligned16(B) || (((uintptr_t)C) & 7)) return MM_ERR_ALIGN;
@@ -902,7 +1009,7 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
       return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'b' ? 3 : 2));
     }();
     const int forced = g_opt_kernel ? g_opt_kernel : forced_env;
-    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 &&
+    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 && !g.swi_I &&
         (int64_t)16 * lda * 2 < 0xFFFFFFFFll && (int64_t)16 * ldb * 2 < 0xFFFFFFFFll) {   // decode: stream W once
       dim3 grid((unsigned)((N + 15) / 16)), block(512);
       hipLaunchKernelGGL(gemm_skinny_kernel, grid, block, 0, s, g);
@@ -914,7 +1021,8 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
     const int64_t tiles_128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
     const int64_t tiles_256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     int variant = 0;   // 0 = v1 (128x128 register staged); DMA tiles: 1 = 256x128, 2 = 256x256, 3 = 128x128, 4 = 64x128, 5 = 64x64
-    if (fits32) {
+    if (g.swi_I) variant = 2;                 // the fused gate|up tile is defined on the 256x256 kernel only
+    else if (fits32) {
       if (forced >= 2 && forced <= 6) variant = forced - 1;
       else if (forced == 0 && tiles_128 >= 192) variant = MM_DEFAULT_DMA_VARIANT(tiles_256);
       else if (forced == 0) variant = small_variant(M, N, K);
@@ -923,14 +1031,14 @@ extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A
       static const int TBM[6] = {0, 256, 256, 128, 64, 64}, TBN[6] = {0, 128, 256, 128, 128, 64};
       const int bm = TBM[variant], bn = TBN[variant];
       g.nbm = (M + bm - 1) / bm;
-      g.nbn = (N + bn - 1) / bn;
+      g.nbn = g.swi_I ? g.swi_I / 128 : (N + bn - 1) / bn;
       const int64_t nwg = (int64_t)g.nbm * g.nbn;
       if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
       const size_t lds = 2 * (bm + bn) * G_BK * 2;
       static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
       // persistent: one resident workgroup per CU walks the tiles; otherwise one tile each
       int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
-      if (g_opt_persist && g_opt_tail && variant == 2) {       // wave quantisation: see the kernel
+      if (g_opt_persist && g_opt_tail && variant == 2 && !g.swi_I) {       // wave quantisation: see the kernel
         const int64_t rem = nwg % ncu;
         if (rem > 0 && 2 * rem <= ncu) {
           g.tail = (int)rem;

@@ -351,6 +351,57 @@ def swiglu(gu, I):
     return SwiGLUFn.apply(gu, I)
 
 
+class SwiGLUMLPFn(torch.autograd.Function):
+    """y = down_proj(silu(gate_proj(x)) * up_proj(x)) + residual as ONE autograd node (HF:llama:163-176 + the residual add of
+    :317).  Forward: the SwiGLU is the epilogue of the fused gate|up GEMM (mm_gemm_swiglu_fwd), the residual the epilogue of
+    down_proj.  Backward: d(gate|up) comes straight out of down_proj's dgrad GEMM (mm_gemm_swiglu_bwd); d(act) never exists
+    in HBM.  Falls back to the separate swiglu kernels when a shape does not qualify (same arithmetic, bit-identical)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, dummy, wgu: ParamGroup, wd: ParamGroup, I: int):
+        fused = K.gemm_swiglu_fwd(x, wgu.tensor(), I)
+        if fused is None:
+            gu = K.linear_fwd(x, wgu.tensor())
+            act = K.swiglu_fwd(gu, I)
+        else:
+            gu, act = fused
+        y = K.linear_fwd(act, wd.tensor(), residual=residual)
+        ctx.wgu, ctx.wd, ctx.I = wgu, wd, I
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, gu, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gu, act = ctx.saved_tensors
+        wgu, wd, I = ctx.wgu, ctx.wd, ctx.I
+        if dy.stride(-1) != 1 or (dy.stride(0) % 8):
+            dy = dy.contiguous()
+        dres = dy if ctx.has_res else None
+
+        def wgrad(d_out, inp, group):
+            if not group.requires_grad:
+                return
+            if _is_deferred(group.params[0]):
+                _defer["items"].append((d_out, inp, group))
+            else:
+                g, acc = group.grad_target()
+                K.linear_wgrad(d_out, inp, g, acc)
+                group.ready()
+
+        wgrad(dy, act, wd)
+        dgu = K.gemm_swiglu_bwd(dy, wd.tensor(), gu, I)
+        if dgu is None:
+            dgu = K.swiglu_bwd(gu, K.linear_dgrad(dy, wd.tensor()), I)
+        wgrad(dgu, x, wgu)
+        dx = K.linear_dgrad(dgu, wgu.tensor()) if ctx.needs_input_grad[0] else None
+        return dx, dres, None, None, None, None
+
+
+def swiglu_mlp(x, wgu, wd, I, residual=None, dummy=None):
+    return SwiGLUMLPFn.apply(x, residual, dummy, as_group(wgu), as_group(wd), I)
+
+
 class AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

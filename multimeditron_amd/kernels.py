@@ -86,6 +86,33 @@ def linear_wgrad(dy2d, x2d, out, accumulate):
     return gemm(GEMM_TN, dy2d, x2d, N, K, M, out=out, accumulate=accumulate)
 
 
+import os as _os
+_FUSED_SWIGLU = _os.environ.get("MM_FUSED_SWIGLU", "1") != "0"      # A/B switch (bench only): 0 = GEMM + separate SwiGLU kernels
+
+
+def gemm_swiglu_fwd(x2d, wgu, I):
+    """(gu [M, 2I], act [M, I]) = fused gate|up GEMM + SwiGLU; None when the shape must take the two-launch form."""
+    M, K = x2d.shape
+    if x2d.dtype != torch.bfloat16 or (I % 128) or (K % 64) or M < 256 or not _FUSED_SWIGLU:
+        return None
+    gu = torch.empty((M, 2 * I), dtype=x2d.dtype, device=x2d.device)
+    act = torch.empty((M, I), dtype=x2d.dtype, device=x2d.device)
+    call("mm_gemm_swiglu_fwd", dt(x2d), M, I, K, _p(x2d), x2d.stride(0), _p(wgu), wgu.stride(0), _p(gu), gu.stride(0), _p(act),
+         act.stride(0), _stream())
+    return gu, act
+
+
+def gemm_swiglu_bwd(dy2d, wd, gu, I):
+    """dgu [M, 2I] from dy [M, H], down_proj weight [H, I] and the saved pre-activations; None -> two-launch form."""
+    M, H = dy2d.shape
+    if dy2d.dtype != torch.bfloat16 or (I % 4) or not _FUSED_SWIGLU:
+        return None
+    dgu = torch.empty_like(gu)
+    call("mm_gemm_swiglu_bwd", dt(dy2d), M, I, H, _p(dy2d), dy2d.stride(0), _p(wd), wd.stride(0), _p(gu), gu.stride(0), _p(dgu),
+         dgu.stride(0), _stream())
+    return dgu
+
+
 def colsum(x2d, out, accumulate):
     call("mm_colsum", dt(x2d), _p(x2d), x2d.shape[0], x2d.shape[1], x2d.stride(0), _p(out), int(accumulate), _stream())
     return out

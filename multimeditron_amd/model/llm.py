@@ -147,9 +147,8 @@ class DecoderLayer(nn.Module):
             o = cache.attend(qkv, cos, sin, key_mask, B, S, a)
         x = a.o_proj(o, residual=x)
         h, x = self.post_attention_layernorm(x)
-        gu = Fm.linear(h, self.mlp._wgu, None, dummy=grad_dummy(self.mlp.gate_proj.weight))
-        act = Fm.swiglu(gu, self.mlp.I)
-        return self.mlp.down_proj(act, residual=x)
+        return Fm.swiglu_mlp(h, self.mlp._wgu, self.mlp.down_proj.weight, self.mlp.I, residual=x,
+                             dummy=grad_dummy(self.mlp.gate_proj.weight))
 
 
 class LayerKVCache:

@@ -669,3 +669,28 @@ def test_adamw_and_gradnorm(K, dtype):
         K.adamw_step(pg, g.cuda(), master, m, v, 1e-2, 0.9, 0.95, 1e-8, 0.01, step, clip=total)
     assert rel(master, ref_p.detach()) < 1e-5
     assert rel(pg.float(), ref_p.detach()) < (1e-5 if dtype == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("M,I,Kd", [(512, 256, 128), (300, 128, 64), (1024, 384, 320), (2048, 14336 // 8, 512)])
+def test_fused_swiglu_gemm_bit_identical_to_two_launch_form(K, M, I, Kd):
+    """mm_gemm_swiglu_fwd / _bwd (SwiGLU as the epilogue of the gate|up GEMM and of down_proj's dgrad) against the separate
+    launches they replace (mm_gemm + mm_swiglu_fwd, mm_gemm NN + mm_swiglu_bwd): same products in the same K order and the
+    same rounding points, so the outputs must be BIT-identical; and both against fp32 torch within bf16 tolerance."""
+    dtype = torch.bfloat16
+    x = rnd((M, Kd), dtype, 201).cuda()
+    wgu = rnd((2 * I, Kd), dtype, 202, 0.05).cuda()
+    H = 192
+    wd = rnd((H, I), dtype, 203, 0.05).cuda()
+    dy = rnd((M, H), dtype, 204).cuda()
+    fused = K.gemm_swiglu_fwd(x, wgu, I)
+    assert fused is not None
+    gu_f, act_f = fused
+    gu = K.linear_fwd(x, wgu)
+    act = K.swiglu_fwd(gu, I)
+    assert torch.equal(gu_f, gu) and torch.equal(act_f, act)
+    ref_gu = x.float() @ wgu.float().t()
+    ref_act = F.silu(ref_gu[:, :I]) * ref_gu[:, I:]
+    assert rel(act_f.float(), ref_act) < 2e-2
+    dgu_f = K.gemm_swiglu_bwd(dy, wd, gu, I)
+    dgu = K.swiglu_bwd(gu, K.linear_dgrad(dy, wd), I)
+    assert dgu_f is not None and torch.equal(dgu_f, dgu)
