@@ -287,22 +287,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // delta[b,h,q] = sum_d dO*O
+// delta[b,hq,q] = sum_d O[b,q,hq,d] * dO[b,q,hq,d] (the softmax-backward row term).  16-byte loads: a row of D elements is
+// read by D/VN lanes and reduced by shuffles (was: one wave per row with 2-byte loads, 3.2 TB/s on 134 MB).
 template <typename T>
 __global__ void attn_delta_kernel(const T* o, const T* dout, int B, int Sq, int Hq, int D, float* delta) {
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  constexpr int VN = Vec16<T>::N;
+  const int lpr = D / VN;                                  // lanes per row: 16 (bf16 D=128), 8 (bf16 D=64), ...
   const int64_t total = (int64_t)B * Sq * Hq;
-  if (wave >= total) return;
-  const int hq = wave % Hq;
-  const int64_t bs = wave / Hq;
-  const int qi = (int)(bs % Sq);
-  const int b = (int)(bs / Sq);
-  const T* op = o + (int64_t)wave * D;
-  const T* dp = dout + (int64_t)wave * D;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool vec = (D % VN) == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+  if (!vec) {                                              // odd head widths (fp32 parity path): one wave per row
+    const int64_t wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= total) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += to_f32(o[wave * D + d]) * to_f32(dout[wave * D + d]);
+    s = wave_sum(s);
+    if (lane == 0) {
+      const int hq = (int)(wave % Hq);
+      const int64_t bs = wave / Hq;
+      delta[((bs / Sq) * Hq + hq) * Sq + bs % Sq] = s;
+    }
+    return;
+  }
+  const int64_t row = tid / lpr;
+  const int c = (int)(tid % lpr);
   float s = 0.f;
-  for (int d = lane; d < D; d += 64) s += to_f32(op[d]) * to_f32(dp[d]);
-  s = wave_sum(s);
-  if (lane == 0) delta[((int64_t)b * Hq + hq) * Sq + qi] = s;
+  if (row < total) {
+    const Vec16<T> a = *(const Vec16<T>*)(o + row * D + c * VN), d = *(const Vec16<T>*)(dout + row * D + c * VN);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) s += a.get(k) * d.get(k);
+  }
+  for (int off = lpr >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (row < total && c == 0) {
+    const int hq = (int)(row % Hq);
+    const int64_t bs = row / Hq;
+    delta[((bs / Sq) * Hq + hq) * Sq + bs % Sq] = s;
+  }
 }
 
 // ============================================================================================================
@@ -1630,10 +1651,15 @@ extern "C" int mm_attn_bwd(int dtype, const void* q, const void* k, const void* 
   const int64_t rows = (int64_t)B * Sq * Hq;
   if (dtype == MM_BF16) {
     if ((q_sb | q_ss | q_sh | k_sb | k_ss | k_sh | v_sb | v_ss | v_sh) & 7) return MM_ERR_ALIGN;
-    hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, B, Sq, Hq, D, delta);
+    hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3((unsigned)((rows * (D / 8) + 255) / 256)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, B, Sq, Hq, D, delta);
     rc = D == 128 ? launch_bf16_bwd<128>(a, s) : launch_bf16_bwd<64>(a, s);
   } else {
-    hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const float*)out, (const float*)dout, B, Sq, Hq, D, delta);
+    {
+      const int lpr = D / 4;
+      const bool vec = (D % 4) == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+      const int64_t nthr = vec ? rows * lpr : rows * 64;
+      hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)out, (const float*)dout, B, Sq, Hq, D, delta);
+    }
     const size_t lds = (size_t)(2 * Skv + 2 * D) * sizeof(float);
     hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(Sq, Hq, B), dim3(64), lds, s, a, D);
   }
