@@ -202,6 +202,10 @@ int mm_ce_bwd(int dtype, const void* logits, int T, int V, int ld, const int64_t
               const float* loss_and_count, const float* gscale, void* dlogits, void* stream);
 /* next-token selection of model.py:607-621: argmax(softmax(logits/T)) over the LAST dim, first max wins          */
 int mm_argmax_softmax(int dtype, const void* logits, int rows, int V, int ld, float temperature, int64_t* out, void* stream);
+/* generate()'s per-token bookkeeping ON the device (the reference syncs per token: model.py:618-625,637-638): id = finished[b]
+ * ? eos : tok[b]; finished[b] |= id == eos; out[b, col] = id; next_ids[b] = id (the next step's embedding lookup).       */
+int mm_decode_select(const int64_t* tok, unsigned char* finished, int64_t eos, int B, int64_t* out, int ld_out, int col,
+                     int64_t* next_ids, void* stream);
 
 /* ---- optimizer: AdamW (config_alignment.yaml:38-59 -> torch.optim.AdamW semantics) + grad-norm clip ----------------
  * sumsq partial: out[blk] = sum g^2 over a slice; mm_gradnorm_finish: total[0] = sqrt(sum) ; clip coef in total[1]  */

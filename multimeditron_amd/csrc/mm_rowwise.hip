@@ -506,15 +506,24 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* logits, int V, int
 // (first index wins).
 template <typename T>
 __global__ __launch_bounds__(1024) void argmax_softmax_kernel(const T* logits, int V, int ld, float temperature, int64_t* out) {
-  constexpr int NT = 1024, NW = NT / 64;      // one row per block, 16 waves sweep the vocabulary three times
+  constexpr int NT = 1024, NW = NT / 64, VN = Vec16<T>::N;      // one row per block, 16 waves sweep the vocabulary three times
   __shared__ float red[NW];
   __shared__ float bestv[NW];
   __shared__ int besti[NW];
   const int row = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const T* p = logits + (int64_t)row * ld;
-  auto scaled = [&](int e) { return to_f32(from_f32<T>(to_f32(p[e]) / temperature)); };   // logits / T in the storage type
+  auto sc1 = [&](float x) { return to_f32(from_f32<T>(x / temperature)); };   // logits / T in the storage type
+  // 16-byte loads (the row stride is a multiple of 16 bytes for the padded logits of the decoder; scalar loads otherwise and
+  // for the ragged tail): each sweep was 125 dependent 2-byte loads per thread at V = 128 258 (115 us per token)
+  const bool vec = ((ld * (int)sizeof(T)) & 15) == 0 && ((uintptr_t)logits & 15) == 0;
+  const int Vv = vec ? V / VN * VN : 0;
   float mx = -INFINITY;
-  for (int e = threadIdx.x; e < V; e += NT) mx = fmaxf(mx, scaled(e));
+  for (int e = threadIdx.x * VN; e < Vv; e += NT * VN) {
+    const Vec16<T> v = *(const Vec16<T>*)(p + e);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) mx = fmaxf(mx, sc1(v.get(k)));
+  }
+  for (int e = Vv + threadIdx.x; e < V; e += NT) mx = fmaxf(mx, sc1(to_f32(p[e])));
   mx = wave_max(mx);
   if (l == 0) red[w] = mx;
   __syncthreads();
@@ -523,7 +532,12 @@ __global__ __launch_bounds__(1024) void argmax_softmax_kernel(const T* logits, i
   for (int i = 1; i < NW; ++i) mx = fmaxf(mx, red[i]);
   __syncthreads();
   float sm = 0.f;
-  for (int e = threadIdx.x; e < V; e += NT) sm += expf(scaled(e) - mx);
+  for (int e = threadIdx.x * VN; e < Vv; e += NT * VN) {
+    const Vec16<T> v = *(const Vec16<T>*)(p + e);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) sm += expf(sc1(v.get(k)) - mx);
+  }
+  for (int e = Vv + threadIdx.x; e < V; e += NT) sm += expf(sc1(to_f32(p[e])) - mx);
   sm = wave_sum(sm);
   if (l == 0) red[w] = sm;
   __syncthreads();
@@ -532,9 +546,18 @@ __global__ __launch_bounds__(1024) void argmax_softmax_kernel(const T* logits, i
   for (int i = 0; i < NW; ++i) sm += red[i];
   float bv = -1.f;
   int bi = 0x7FFFFFFF;
-  for (int e = threadIdx.x; e < V; e += NT) {
-    const float pr = to_f32(from_f32<T>(expf(scaled(e) - mx) / sm));
-    if (pr > bv) { bv = pr; bi = e; }
+  // (value desc, index asc): a thread meets its elements in ascending index order, so `>` keeps the first of equals
+  for (int e = threadIdx.x * VN; e < Vv; e += NT * VN) {
+    const Vec16<T> v = *(const Vec16<T>*)(p + e);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+      const float pr = to_f32(from_f32<T>(expf(sc1(v.get(k)) - mx) / sm));
+      if (pr > bv) { bv = pr; bi = e + k; }
+    }
+  }
+  for (int e = Vv + threadIdx.x; e < V; e += NT) {
+    const float pr = to_f32(from_f32<T>(expf(sc1(to_f32(p[e])) - mx) / sm));
+    if (pr > bv || (pr == bv && e < bi)) { bv = pr; bi = e; }
   }
   // first index wins among equal probabilities: (value desc, index asc) order in every merge
 #pragma unroll
@@ -811,6 +834,29 @@ extern "C" int mm_argmax_softmax(int dtype, const void* logits, int rows, int V,
     hipLaunchKernelGGL(argmax_softmax_kernel<bf16>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const bf16*)logits, V, ld, temperature, out);
   else
     hipLaunchKernelGGL(argmax_softmax_kernel<float>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, (const float*)logits, V, ld, temperature, out);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+// generate()'s per-token bookkeeping on the device (reference model.py:618-625 does it on the host after a sync): a row that
+// has already emitted eos keeps emitting eos, `finished` is updated, the chosen id goes to column `col` of the output and
+// to `next_ids` (the next step's embedding lookup).
+__global__ void decode_select_kernel(const int64_t* tok, unsigned char* finished, int64_t eos, int B, int64_t* out, int ld_out, int col,
+                                     int64_t* next_ids) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int64_t t = finished[b] ? eos : tok[b];
+  finished[b] = (unsigned char)(finished[b] | (t == eos));
+  out[(int64_t)b * ld_out + col] = t;
+  next_ids[b] = t;
+}
+
+extern "C" int mm_decode_select(const int64_t* tok, unsigned char* finished, int64_t eos, int B, int64_t* out, int ld_out, int col,
+                                int64_t* next_ids, void* stream) {
+  if (!tok || !finished || !out || !next_ids || B < 0 || col < 0 || col >= ld_out) return MM_ERR_ARG;
+  if (B == 0) return MM_OK;
+  hipLaunchKernelGGL(decode_select_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tok, finished, eos, B, out, ld_out, col,
+                     next_ids);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

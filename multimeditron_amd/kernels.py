@@ -393,6 +393,11 @@ def argmax_softmax(logits2d, V, temperature):
     return out
 
 
+def decode_select(tok, finished, eos, out, col, next_ids):
+    """device-side eos bookkeeping of one decode step (no host sync): see mm_decode_select."""
+    call("mm_decode_select", _p(tok), _p(finished), int(eos), tok.numel(), _p(out), out.stride(0), int(col), _p(next_ids), _stream())
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def gradnorm(flat_grads, max_norm):
     """flat_grads: list of 1-D flat gradient buffers -> device tensor [2] = (total_norm, clip_coef)."""

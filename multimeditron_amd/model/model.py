@@ -214,25 +214,96 @@ class MultiModalModelForCausalLM(nn.Module):
                     own[k].copy_(v.to(device=own[k].device, dtype=own[k].dtype).reshape(own[k].shape))
         return missing, extra
 
-    def save_pretrained(self, path: str):
+    # known-ignorable keys of a reference checkpoint: the reference keeps the whole CLIPModel (text tower, projections,
+    # logit_scale: SURVEY Appendix B) and HF buffers; a tied lm_head is stored under both names
+    _IGNORABLE = ("text_model", "text_projection", "visual_projection", "logit_scale", "position_ids", "post_layernorm",
+                  "rotary_emb.inv_freq")
+
+    def save_pretrained(self, path: str, max_shard_size: int = 5 * 1024 ** 3, safe_serialization: bool = True):
+        """HF layout (reference model.py:152-202 config + `PreTrainedModel.save_pretrained` weights): config.json with
+        `MultimodalConfig.to_dict`, and the weights under the reference's parameter names as `model.safetensors`, or as
+        `model-0000i-of-0000N.safetensors` + `model.safetensors.index.json` when they exceed `max_shard_size` (what an 8B
+        checkpoint looks like).  Waits for in-flight device work first (the trainer's AdamW runs on a side stream)."""
         from safetensors.torch import save_file
         os.makedirs(path, exist_ok=True)
         self.config.save_pretrained(path)
-        with open(os.path.join(path, "llm_config.json"), "w") as f:
-            json.dump(self._llm_cfg.to_dict(), f, indent=2)
-        sd = {k: v.detach().cpu().contiguous().clone() for k, v in self.named_parameters()}
-        save_file(sd, os.path.join(path, "model.safetensors"))
+        try:                                       # the LLM shape travels with the checkpoint only when llm_path cannot name it
+            resolve_llm_config(self.config.llm_path)
+        except (ValueError, OSError):
+            with open(os.path.join(path, "llm_config.json"), "w") as f:
+                json.dump(self._llm_cfg.to_dict(), f, indent=2)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        names = [(k, v) for k, v in self.named_parameters()]
+        shards, cur, cur_bytes = [], [], 0
+        for k, v in names:
+            nb = v.numel() * v.element_size()
+            if cur and cur_bytes + nb > max_shard_size:
+                shards.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append((k, v))
+            cur_bytes += nb
+        if cur:
+            shards.append(cur)
+        if len(shards) == 1:
+            save_file({k: v.detach().cpu().contiguous().clone() for k, v in shards[0]}, os.path.join(path, "model.safetensors"),
+                      metadata={"format": "pt"})
+            return
+        weight_map, total = {}, 0
+        for i, sh in enumerate(shards):
+            fn = f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file({k: v.detach().cpu().contiguous().clone() for k, v in sh}, os.path.join(path, fn), metadata={"format": "pt"})
+            for k, v in sh:
+                weight_map[k] = fn
+                total += v.numel() * v.element_size()
+        with open(os.path.join(path, "model.safetensors.index.json"), "w") as f:
+            json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=2, sort_keys=True)
+
+    def load_checkpoint_weights(self, path: str, strict: bool = True):
+        """Stream `model.safetensors` or the shards listed by `model.safetensors.index.json` into the parameters, tensor by
+        tensor (no whole-checkpoint host copy).  -> (missing, unexpected); raises when strict and either is non-empty
+        after the known-ignorable keys (CLIP text tower etc.) are set aside."""
+        from safetensors import safe_open
+        idx = os.path.join(path, "model.safetensors.index.json")
+        if os.path.exists(idx):
+            files = sorted(set(json.load(open(idx))["weight_map"].values()))
+        elif os.path.exists(os.path.join(path, "model.safetensors")):
+            files = ["model.safetensors"]
+        else:
+            raise FileNotFoundError(f"{path}: neither model.safetensors nor model.safetensors.index.json")
+        own = dict(self.named_parameters())
+        seen, unexpected = set(), []
+        tied = self._llm_cfg.tie_word_embeddings
+        with torch.no_grad():
+            for fn in files:
+                with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as f:
+                    for k in f.keys():
+                        if k == "model.lm_head.weight" and tied:
+                            continue
+                        if k not in own:
+                            if not any(t in k for t in self._IGNORABLE):
+                                unexpected.append(k)
+                            continue
+                        p = own[k]
+                        p.copy_(f.get_tensor(k).to(dtype=p.dtype).reshape(p.shape))
+                        seen.add(k)
+        missing = [k for k in own if k not in seen]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"{path}: missing keys {missing[:8]}{'...' if len(missing) > 8 else ''}; "
+                               f"unexpected keys {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
+        if missing or unexpected:
+            logger.warning(f"{path}: {len(missing)} missing / {len(unexpected)} unexpected keys (left at their initial values)")
+        return missing, unexpected
 
     @classmethod
-    def from_pretrained(cls, path: str, device=None, **kwargs):
-        from safetensors.torch import load_file
+    def from_pretrained(cls, path: str, device=None, strict: bool = True, **kwargs):
         cfg = MultimodalConfig.from_dict(json.load(open(os.path.join(path, "config.json"))))
         llm_cfg = None
         p = os.path.join(path, "llm_config.json")
         if os.path.exists(p):
             llm_cfg = json.load(open(p))
         model = cls(cfg, device=device, llm_config=llm_cfg)
-        model.load_state_dict(load_file(os.path.join(path, "model.safetensors")), strict=False)
+        model.load_checkpoint_weights(path, strict=strict)
         return model
 
     # ------------------------------------------------------------------ freeze policies (model.py:310-377)
@@ -341,10 +412,17 @@ class MultiModalModelForCausalLM(nn.Module):
                               past_key_values=past_key_values, use_cache=use_cache, labels=labels, return_dict=return_dict,
                               **kwargs)
 
-    def generate(self, batch: Dict[str, Any], max_new_tokens=512, temperature=0.1, do_sample=True, **kwargs) -> torch.Tensor:
+    def generate(self, batch: Dict[str, Any], max_new_tokens=512, temperature=0.1, do_sample=True, sync_every: int = 16,
+                 **kwargs) -> torch.Tensor:
         """model.py:528-640: KV-cache decode.  Token choice = argmax(softmax(logits/T)) (one kernel) or a per-row
         multinomial draw; decode position = padded prompt length + i - 1 for every row (reference quirk :582-586);
-        rows that already emitted eos keep emitting eos; returns [B, n_new] int64 on CPU without the prompt."""
+        rows that already emitted eos keep emitting eos; returns [B, n_new] int64 on CPU without the prompt.
+
+        The reference synchronises with the host after EVERY token (`.cpu()`, `finished.all()`, model.py:618-625,637-638).
+        Here the chosen id, the eos bookkeeping and the next embedding lookup stay on the device (mm_decode_select +
+        the embedding gather), so the host queues steps ahead of the GPU; it looks at `finished` only every `sync_every`
+        tokens.  Steps issued past the point where every row had finished are cut off afterwards: the returned ids are
+        exactly the reference's (same length, same values)."""
         if self._flat is None:
             self.pack_parameters()
         dev = self.device
@@ -353,33 +431,47 @@ class MultiModalModelForCausalLM(nn.Module):
         B = input_ids.shape[0]
         V = self._llm_cfg.vocab_size
         eos = self.config.eos_token_idx
-        generated = []
-        finished = torch.zeros(B, dtype=torch.bool)
+        if max_new_tokens <= 0:
+            return torch.empty((B, 0), dtype=torch.int64)
         with torch.no_grad():
             nxt = self.embed_modalities_with_text(input_ids, batch["processed_multimodal_inputs"])
             attention_mask = batch["attention_mask"].to(dev)
             position_ids = batch["position_ids"].to(dev)
             seq_length = attention_mask.shape[1]
             cache = self.model.new_cache(B, seq_length + max_new_tokens)
+            # device-resident loop state (plumbing): the growing mask is a view of one preallocated buffer
+            full_mask = torch.ones((B, seq_length + max_new_tokens), dtype=attention_mask.dtype, device=dev)
+            full_mask[:, :seq_length] = attention_mask
+            out_ids = torch.full((B, max_new_tokens), eos, dtype=torch.int64, device=dev)
+            finished = torch.zeros(B, dtype=torch.uint8, device=dev)
+            next_ids = torch.empty(B, dtype=torch.int64, device=dev)
+            steps = 0
+            emb = self.model.get_input_embeddings()
             for i in range(max_new_tokens):
                 if i > 0:
                     position_ids = torch.full((B, 1), seq_length + i - 1, dtype=torch.long, device=dev)
-                    attention_mask = torch.cat([attention_mask, torch.ones((B, 1), dtype=attention_mask.dtype, device=dev)], dim=-1)
+                    attention_mask = full_mask[:, : seq_length + i]
                 out = self.model(inputs_embeds=nxt, attention_mask=attention_mask, position_ids=position_ids,
                                  past_key_values=cache, use_cache=True, logits_to_keep=1)
                 logits2d = out.logits[:, -1, :]                       # [B, V] view, stride padded
                 if do_sample:
                     probs = torch.softmax(logits2d.float() / temperature, dim=-1)
-                    tok = torch.cat([torch.multinomial(p, num_samples=1) for p in probs]).cpu()
+                    tok = torch.multinomial(probs, num_samples=1).view(B)
                 else:
-                    tok = K.argmax_softmax(logits2d, V, temperature).cpu()
-                tok = torch.where(finished, torch.full_like(tok, eos), tok)
-                generated.append(tok)
-                finished = finished | (tok == eos)
-                if bool(finished.all()):
+                    tok = K.argmax_softmax(logits2d, V, temperature)
+                K.decode_select(tok, finished, eos, out_ids, i, next_ids)
+                steps = i + 1
+                if steps == max_new_tokens:
                     break
-                nxt = self.model.get_input_embeddings()(tok.to(dev).view(B, 1))
-        return torch.stack(generated, dim=1)
+                if steps % max(1, sync_every) == 0 and bool(finished.all()):      # the only host sync of the loop
+                    break
+                nxt = emb(next_ids.view(B, 1))
+            ids = out_ids[:, :steps].cpu()
+        # the reference stops right after the first step at which every row has emitted eos
+        done = (ids == eos).to(torch.int8).cummax(dim=1).values.bool().all(dim=0)
+        if bool(done.any()):
+            ids = ids[:, : int(torch.nonzero(done)[0]) + 1]
+        return ids
 
 
 def bootstrap(config, tokenizer, modalities_config):

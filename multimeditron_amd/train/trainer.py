@@ -398,8 +398,79 @@ class MultimodalTrainer:
         """Make the compute stream wait for the in-flight optimiser update (call before reading parameters)."""
         self._wait_optimizer()
 
-    def train(self, batches: Optional[Iterable[Dict[str, Any]]] = None, max_steps: Optional[int] = None):
-        """Minimal loop: iterate collated batches (or collate `train_dataset` with `data_collator` in fixed-size chunks)."""
+    # ------------------------------------------------------------------ checkpoints (reference cli/train.py:186-195)
+    def save_model(self, path: str, **kw):
+        """Weights only, safe against the side-stream optimizer: waits for the in-flight AdamW before the copy."""
+        self._wait_optimizer()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.model.save_pretrained(path, **kw)
+
+    def _state_signature(self):
+        return {"ranges": [[int(s), int(e), bool(d)] for s, e, d in self.ranges], "training_mode": self.training_mode.name,
+                "numel": int(self.master.numel())}
+
+    def save_state(self, path: str):
+        """HF-Trainer-style `checkpoint-N` directory: the model (reference layout) + what a bit-exact resume needs beyond it:
+        the fp32 master weights and AdamW moments of the trainable ranges, the step counter and the schedule parameters
+        (the reference gets the same from DeepSpeed's optimizer shards, config/deepspeed.json + trainer.train(
+        resume_from_checkpoint=...)).  No RNG state: the path has no dropout."""
+        import json
+        from safetensors.torch import save_file
+        self.save_model(path)
+        save_file({"master": self.master.detach().cpu(), "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu()},
+                  os.path.join(path, "optimizer_state.safetensors"), metadata={"format": "pt"})
+        with open(os.path.join(path, "trainer_state.json"), "w") as f:
+            json.dump({"global_step": self.step_count, "micro_step": self._micro, "learning_rate": self.lr, "min_lr": self.min_lr,
+                       "max_steps": self.max_steps, "warmup_steps": self.warmup, "weight_decay": self.wd, "betas": list(self.betas),
+                       "eps": self.eps, "max_grad_norm": self.max_grad_norm, "gradient_accumulation_steps": self.accum,
+                       "signature": self._state_signature()}, f, indent=2)
+
+    def load_state(self, path: str, load_model: bool = True):
+        """Resume from `save_state`: weights (streamed shard by shard), fp32 master / moments, step counter.  The master
+        weights are authoritative: the bf16 parameters are re-derived from them, so the continued run is bit-identical
+        to the uninterrupted one."""
+        import json
+        from safetensors import safe_open
+        st = json.load(open(os.path.join(path, "trainer_state.json")))
+        if st["signature"] != self._state_signature():
+            raise ValueError(f"{path}: optimizer state was saved for a different trainable set / training mode "
+                             f"({st['signature']['training_mode']}, {st['signature']['numel']} elements)")
+        self._wait_optimizer()
+        if load_model:
+            self.model.load_checkpoint_weights(path, strict=True)
+        with safe_open(os.path.join(path, "optimizer_state.safetensors"), framework="pt", device="cpu") as f:
+            self.master.copy_(f.get_tensor("master"))
+            self.m.copy_(f.get_tensor("exp_avg"))
+            self.v.copy_(f.get_tensor("exp_avg_sq"))
+        with torch.no_grad():
+            for (s0, e0, _), off in zip(self.ranges, self.state_off):
+                self.flat.data[s0:e0].copy_(self.master[off:off + e0 - s0])       # bf16 parameters = round(master)
+        self.step_count = int(st["global_step"])
+        self._micro = 0
+        return st
+
+    def train(self, batches: Optional[Iterable[Dict[str, Any]]] = None, max_steps: Optional[int] = None,
+              resume_from_checkpoint: Optional[str] = None, per_device_train_batch_size: int = 4):
+        """Minimal loop: iterate collated batches, or (batches=None) collate `train_dataset` with `data_collator` in chunks
+        of `per_device_train_batch_size`, staged to the device by DevicePrefetcher.  `resume_from_checkpoint` = a
+        `save_state` directory (reference cli/train.py:188-195)."""
+        if resume_from_checkpoint:
+            self.load_state(resume_from_checkpoint)
+        if batches is None:
+            if self.train_dataset is None or self.data_collator is None:
+                raise ValueError("train(): give `batches`, or construct the trainer with train_dataset and data_collator")
+            ds, bs, coll = self.train_dataset, per_device_train_batch_size, self.data_collator
+            rank = self.dist.get_rank(self.pg) if self.dist else 0
+
+            def gen():      # contiguous chunks, strided over ranks (each rank sees a disjoint share)
+                for i in range(rank * bs, len(ds) - bs + 1, bs * self.world):
+                    yield coll([ds[j] for j in range(i, i + bs)])
+
+            batches = gen()
+            if torch.cuda.is_available():
+                from .prefetch import DevicePrefetcher
+                batches = DevicePrefetcher(batches, device=self.flat.device)
         losses = []
         steps = max_steps or self.max_steps or 0
         for i, batch in enumerate(batches):

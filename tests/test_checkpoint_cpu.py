@@ -36,3 +36,54 @@ def test_reference_named_weights_roundtrip(golden_dir, tmp_path):
     for (k1, p1), (k2, p2) in zip(m.named_parameters(), m2.named_parameters()):
         assert k1 == k2 and torch.equal(p1.detach(), p2.detach()), k1
     assert set(dict(m.named_parameters())) == {k for k in w if not (k == "model.lm_head.weight" and meta["llm"].get("tie_word_embeddings"))}
+
+
+def test_sharded_checkpoint_and_missing_keys(golden_dir, tmp_path):
+    """An 8B checkpoint is sharded (`model-0000i-of-0000N.safetensors` + `model.safetensors.index.json`): write one (tiny
+    shard limit), read it back tensor by tensor, and make a missing / unexpected key an ERROR instead of silent random init
+    (model.py:235)."""
+    import pytest
+    from safetensors.torch import load_file, save_file
+    from multimeditron_amd.model.model import MultiModalModelForCausalLM
+    meta, w, v = R.load_golden("tiny_clip_llama", golden_dir)
+    m = build_from_golden(meta, w, tmp_path / "a", "float32", device="cpu")
+    out = tmp_path / "sharded"
+    m.save_pretrained(str(out), max_shard_size=200_000)
+    idx = json.load(open(out / "model.safetensors.index.json"))
+    files = sorted(set(idx["weight_map"].values()))
+    assert len(files) > 3 and all(os.path.exists(out / f) for f in files) and not os.path.exists(out / "model.safetensors")
+    assert set(idx["weight_map"]) == set(dict(m.named_parameters()))
+    m2 = MultiModalModelForCausalLM.from_pretrained(str(out), device="cpu")
+    for (k1, p1), (k2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert k1 == k2 and torch.equal(p1.detach(), p2.detach()), k1
+    # drop one tensor from a shard: strict load must name it; non-strict leaves it at init and reports it
+    victim = "model.model.layers.1.mlp.down_proj.weight"
+    fn = out / idx["weight_map"][victim]
+    sd = load_file(str(fn))
+    sd.pop(victim)
+    sd["model.model.layers.1.mlp.bogus.weight"] = torch.zeros(2, 2)
+    save_file(sd, str(fn))
+    with pytest.raises(RuntimeError) as e:
+        MultiModalModelForCausalLM.from_pretrained(str(out), device="cpu")
+    assert victim in str(e.value) and "bogus" in str(e.value)
+    m3 = MultiModalModelForCausalLM.from_pretrained(str(out), device="cpu", strict=False)
+    missing, unexpected = m3.load_checkpoint_weights(str(out), strict=False)
+    assert missing == [victim] and unexpected == ["model.model.layers.1.mlp.bogus.weight"]
+
+
+def test_checkpoint_needs_no_side_file_when_llm_path_resolves(tmp_path):
+    """`llm_config.json` is written only when config.llm_path cannot name the LLM shape."""
+    from multimeditron_amd.model.model import MultimodalConfig, MultiModalModelForCausalLM
+    d = tmp_path / "llm"
+    os.makedirs(d)
+    json.dump(dict(model_type="llama", hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2,
+                   num_key_value_heads=1, head_dim=32, vocab_size=50, rms_norm_eps=1e-5, tie_word_embeddings=False,
+                   rope_parameters={"rope_type": "default", "rope_theta": 10000.0}), open(d / "config.json", "w"))
+    cfg = MultimodalConfig(vocab_size=52, modalities=[], llm_path=str(d), dtype="float32", eos_token_idx=1, hidden_size=64)
+    m = MultiModalModelForCausalLM(cfg, device="cpu")
+    out = tmp_path / "ck"
+    m.save_pretrained(str(out))
+    assert not os.path.exists(out / "llm_config.json")
+    m2 = MultiModalModelForCausalLM.from_pretrained(str(out), device="cpu")
+    for (k1, p1), (k2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert k1 == k2 and torch.equal(p1.detach(), p2.detach())
