@@ -207,6 +207,14 @@ int mm_argmax_softmax(int dtype, const void* logits, int rows, int V, int ld, fl
 int mm_decode_select(const int64_t* tok, unsigned char* finished, int64_t eos, int B, int64_t* out, int ld_out, int col,
                      int64_t* next_ids, void* stream);
 
+/* ---- MoE image modality: gating-weighted fusion of the experts' token features (modalities/image_modality_moe.py:163-205)
+ * X [E, n, L] (L = P*C, expert-major), gate [n, E] fp32 (the gating network's softmax weights, expert order), idx[J] = the
+ * experts taking part (host array).  mode 0: out[n, L] = sum_j gate[n, idx[j]] * X[idx[j], n]  (`weighted_average`, :170-176);
+ * mode 1: out[n, J, L] = softmax_j(gate[n, idx[.]])[j] * X[idx[j], n]  (the specialists' scaled contexts of `cross_attn`,
+ * :186-199).  backward = 1: X is d(out), out is dX [E, n, L] (only the listed experts' slices are written).                */
+int mm_expert_fuse(int dtype, int backward, int mode, const void* X, const float* gate, const int* idx, int J, int E, int n,
+                   int64_t L, void* out, void* stream);
+
 /* ---- optimizer: AdamW (config_alignment.yaml:38-59 -> torch.optim.AdamW semantics) + grad-norm clip ----------------
  * sumsq partial: out[blk] = sum g^2 over a slice; mm_gradnorm_finish: total[0] = sqrt(sum) ; clip coef in total[1]  */
 int mm_gradnorm_partial(int dtype, const void* g, int64_t n, float* partial, int nblk, void* stream);

@@ -575,6 +575,63 @@ __global__ __launch_bounds__(1024) void argmax_softmax_kernel(const T* logits, i
   }
 }
 
+// ---------------------------------------------------------------- MoE expert fusion (image_modality_moe.py:163-205)
+// X [E, n, L] = the experts' token features (L = P*C), gate [n, E] fp32 = the gating network's softmax weights.
+//   mode 0 (weighted_average, :170-176): out[n, L]    = sum_j  w(n, idx[j]) * X[idx[j], n, :]
+//   mode 1 (cross_attn contexts, :190-199): out[n, j, L] = w'(n, j) * X[idx[j], n, :],  w' = softmax over the J listed experts
+// fp32 arithmetic, one rounding.  Backward: dX[idx[j], n, :] = w * dout (mode 0: dout[n, :], mode 1: dout[n, j, :]).
+constexpr int MOE_MAXJ = 16;
+struct MoeIdx { int v[MOE_MAXJ]; };
+
+template <typename T, bool BWD>
+__global__ void expert_fuse_kernel(const T* X, const float* gate, MoeIdx idx, int J, int E, int n, int64_t L, int mode, T* out) {
+  constexpr int VN = Vec16<T>::N;
+  const int64_t per = L / VN;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n * per) return;
+  const int b = (int)(i / per);
+  const int64_t c = (i % per) * VN;
+  float w[MOE_MAXJ];
+  float mx = -INFINITY, sm = 0.f;
+  for (int j = 0; j < J; ++j) { w[j] = gate[(int64_t)b * E + idx.v[j]]; mx = fmaxf(mx, w[j]); }
+  if (mode == 1) {
+    for (int j = 0; j < J; ++j) { w[j] = expf(w[j] - mx); sm += w[j]; }
+    for (int j = 0; j < J; ++j) w[j] /= sm;
+  }
+  if (!BWD) {
+    if (mode == 0) {
+      float acc[VN];
+#pragma unroll
+      for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+      for (int j = 0; j < J; ++j) {
+        const Vec16<T> x = *(const Vec16<T>*)(X + ((int64_t)idx.v[j] * n + b) * L + c);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) acc[k] += w[j] * x.get(k);
+      }
+      Vec16<T> o;
+#pragma unroll
+      for (int k = 0; k < VN; ++k) o.set(k, acc[k]);
+      *(Vec16<T>*)(out + (int64_t)b * L + c) = o;
+    } else {
+      for (int j = 0; j < J; ++j) {
+        const Vec16<T> x = *(const Vec16<T>*)(X + ((int64_t)idx.v[j] * n + b) * L + c);
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) o.set(k, w[j] * x.get(k));
+        *(Vec16<T>*)(out + ((int64_t)b * J + j) * L + c) = o;
+      }
+    }
+  } else {      // X = dout, out = dX [E, n, L] (slices of the listed experts)
+    for (int j = 0; j < J; ++j) {
+      const Vec16<T> d = *(const Vec16<T>*)(X + (mode == 0 ? (int64_t)b * L : ((int64_t)b * J + j) * L) + c);
+      Vec16<T> o;
+#pragma unroll
+      for (int k = 0; k < VN; ++k) o.set(k, w[j] * d.get(k));
+      *(Vec16<T>*)(out + ((int64_t)idx.v[j] * n + b) * L + c) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- cast
 template <typename S, typename D>
 __global__ void cast_kernel(const S* s, D* d, int64_t n) {
@@ -857,6 +914,33 @@ extern "C" int mm_decode_select(const int64_t* tok, unsigned char* finished, int
   if (B == 0) return MM_OK;
   hipLaunchKernelGGL(decode_select_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tok, finished, eos, B, out, ld_out, col,
                      next_ids);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_expert_fuse(int dtype, int backward, int mode, const void* X, const float* gate, const int* idx, int J, int E, int n,
+                              int64_t L, void* out, void* stream) {
+  if (!X || !gate || !idx || !out || J <= 0 || J > MOE_MAXJ || E <= 0 || n < 0 || L <= 0 || mode < 0 || mode > 1) return MM_ERR_ARG;
+  if (n == 0) return MM_OK;
+  const int vn = dtype == MM_BF16 ? 8 : 4;
+  if ((L % vn) || !mm_aligned16(X) || !mm_aligned16(out)) return MM_ERR_ALIGN;
+  MoeIdx ix{};
+  for (int j = 0; j < J; ++j) {
+    if (idx[j] < 0 || idx[j] >= E) return MM_ERR_ARG;
+    ix.v[j] = idx[j];
+  }
+  const int64_t total = (int64_t)n * (L / vn);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MM_BF16) {
+    if (backward) hipLaunchKernelGGL((expert_fuse_kernel<bf16, true>), grid, block, 0, s, (const bf16*)X, gate, ix, J, E, n, L, mode, (bf16*)out);
+    else hipLaunchKernelGGL((expert_fuse_kernel<bf16, false>), grid, block, 0, s, (const bf16*)X, gate, ix, J, E, n, L, mode, (bf16*)out);
+  } else if (dtype == MM_F32) {
+    if (backward) hipLaunchKernelGGL((expert_fuse_kernel<float, true>), grid, block, 0, s, (const float*)X, gate, ix, J, E, n, L, mode, (float*)out);
+    else hipLaunchKernelGGL((expert_fuse_kernel<float, false>), grid, block, 0, s, (const float*)X, gate, ix, J, E, n, L, mode, (float*)out);
+  } else {
+    return MM_ERR_UNSUPPORTED;
+  }
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

@@ -333,6 +333,64 @@ def attention_head_width(d: int, dtype) -> int:
     return 64 if d < 64 else 128
 
 
+class CrossAttentionFn(torch.autograd.Function):
+    """Non-causal attention of Nq queries over Nkv keys/values with separate inputs (model/attention.py:79-96 between the
+    projections): q2d [n*Nq, h*d], kv2d [n*Nkv, 2*h*d] (k | v, one fused projection output) -> [n*Nq, h*d]."""
+
+    @staticmethod
+    def forward(ctx, q2d, kv2d, n, Nq, Nkv, heads, d, scale):
+        C = heads * d
+        q = q2d.view(n, Nq, heads, d)
+        k = kv2d[:, :C].view(n, Nkv, heads, d)
+        v = kv2d[:, C:].view(n, Nkv, heads, d)
+        out, lse = K.attn_fwd(q, k, v, None, False, scale)
+        ctx.dims = (n, Nq, Nkv, heads, d, scale)
+        ctx.save_for_backward(q2d, kv2d, out, lse)
+        return out.view(n * Nq, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2d, kv2d, out, lse = ctx.saved_tensors
+        n, Nq, Nkv, heads, d, scale = ctx.dims
+        C = heads * d
+        mk = torch.zeros_like if q2d.dtype == torch.float32 else torch.empty_like
+        dq2d, dkv2d = mk(q2d), mk(kv2d)
+        K.attn_bwd(q2d.view(n, Nq, heads, d), kv2d[:, :C].view(n, Nkv, heads, d), kv2d[:, C:].view(n, Nkv, heads, d), out,
+                   dout.contiguous().view(n, Nq, heads, d), lse, None, False, scale, dq2d.view(n, Nq, heads, d),
+                   dkv2d[:, :C].view(n, Nkv, heads, d), dkv2d[:, C:].view(n, Nkv, heads, d))
+        return dq2d, dkv2d, None, None, None, None, None, None
+
+
+def cross_attention(q2d, kv2d, n, Nq, Nkv, heads, d, scale):
+    return CrossAttentionFn.apply(q2d, kv2d, n, Nq, Nkv, heads, d, scale)
+
+
+class ExpertFuseFn(torch.autograd.Function):
+    """Gating-weighted fusion of stacked expert features x [E, n, P, C] (image_modality_moe.py:163-205); `gate` [n, E] fp32 is
+    the gating network's output and receives no gradient here (the gate is not part of this build)."""
+
+    @staticmethod
+    def forward(ctx, x, gate, idx, mode):
+        E, n, P, C = x.shape
+        ctx.meta = (tuple(idx), mode, E, P, C)
+        ctx.save_for_backward(gate)
+        out = K.expert_fuse(x.reshape(E, n, P * C), gate, idx, mode)
+        return out.view(n, P, C) if mode == 0 else out.view(n, len(idx) * P, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (gate,) = ctx.saved_tensors
+        idx, mode, E, P, C = ctx.meta
+        n = dout.shape[0]
+        d = dout.contiguous().view(n, P * C) if mode == 0 else dout.contiguous().view(n, len(idx), P * C)
+        dx = K.expert_fuse(d, gate, idx, mode, backward=True, E=E)
+        return dx.view(E, n, P, C), None, None, None
+
+
+def expert_fuse(x, gate, idx, mode):
+    return ExpertFuseFn.apply(x, gate, list(idx), mode)
+
+
 # --------------------------------------------------------------------------------------------------- activations
 class SwiGLUFn(torch.autograd.Function):
     @staticmethod

@@ -393,6 +393,23 @@ def argmax_softmax(logits2d, V, temperature):
     return out
 
 
+def expert_fuse(x, gate, idx, mode, backward=False, E=None):
+    """MoE fusion (see mm_expert_fuse).  forward: x [E, n, L] -> [n, L] (mode 0) / [n, J, L] (mode 1); backward: x = dout ->
+    dX [E, n, L] (zeros outside the listed experts)."""
+    import ctypes
+    J = len(idx)
+    ix = (ctypes.c_int * J)(*[int(i) for i in idx])
+    if not backward:
+        E_, n, L = x.shape
+        out = torch.empty((n, L) if mode == 0 else (n, J, L), dtype=x.dtype, device=x.device)
+    else:
+        E_ = int(E)
+        n, L = x.shape[0], x.shape[-1]
+        out = torch.zeros((E_, n, L), dtype=x.dtype, device=x.device)
+    call("mm_expert_fuse", dt(x), int(backward), int(mode), _p(x), _p(gate), ix, J, E_, n, L, _p(out), _stream())
+    return out
+
+
 def decode_select(tok, finished, eos, out, col, next_ids):
     """device-side eos bookkeeping of one decode step (no host sync): see mm_decode_select."""
     call("mm_decode_select", _p(tok), _p(finished), int(eos), tok.numel(), _p(out), out.stride(0), int(col), _p(next_ids), _stream())

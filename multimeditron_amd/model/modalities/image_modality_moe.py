@@ -1,0 +1,207 @@
+"""`moe_meditron_clip`: mixture-of-experts image modality (reference model/modalities/image_modality_moe.py:10-246 and
+model/attention.py:5-101) on libmmhip kernels.
+
+E CLIP vision towers ("experts") run on every image; a gating network scores the image; one of three fusions combines the
+experts' patch tokens; the MLP projector maps them into the LLM's embedding space:
+
+    sequence_append   [n, E*P, C]  all experts' tokens one after the other                          (:165-168)
+    weighted_average  [n, P, C]    sum_e w[n,e] * tokens_e                                           (:169-176)
+    cross_attn        [n, P, C]    generalist tokens attend over the specialists' tokens, each scaled by the softmax of the
+                                   specialists' gate weights (CrossAttention, attention.py:48-101)  (:177-203)
+
+What runs where: the towers are this package's `VisionTransformer` (model/vision.py), the fusion is `mm_expert_fuse`, the
+cross-attention is three biased GEMMs + the non-causal flash-attention kernel (Nq = P queries over (E-1)*P keys) + a GEMM.
+Parameter names equal the reference's (`experts.{e}.*`, `cross_attn.{q,k,v}_proj / proj`, `projector.projection.{0,2,4}`).
+
+NOT built: the reference's `GatingNetwork` is a torchvision ResNet-50 (moe/gating.py:37-89); torchvision is
+absent and a ResNet is outside the hot path.  `gating_network` is therefore a plug: any callable with the reference's output
+contract `pixels [n,3,H,W] -> (logits [n,E], topk_indices, weights [n,E])`.  The experts run one after the other (E x the
+single-tower launches); batching them as one grouped GEMM is the next step.  `CrossAttention`'s dropout (p = 0.1, active in the
+reference whenever the module is in train mode) is not implemented: outputs equal the reference in eval mode."""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import functional as Fm
+from ...nn import Linear, grad_dummy
+from ..constants import MODALITY_VALUE_KEY, NUM_EMBEDDINGS_KEY
+from ..presets import resolve_preprocessor_config, resolve_vision_config
+from ..projectors.mlp import MLPProjector
+from ..vision import VisionConfig, VisionTransformer
+from .base import AutoModality, BaseModality, BaseModalityConfig, BaseModalityProcessor
+from .image_modality import ClipImagePreprocessor
+
+
+class MOEImageConfig(BaseModalityConfig):
+    """reference image_modality_moe.py:10-52 (same arguments)."""
+
+    def __init__(self, hidden_size: int = 1024, use_bias_proj: bool = True, expert_clip_names: Optional[List[str]] = None,
+                 image_processor: str = "openai/clip-vit-large-patch14", gating_path: str = "", top_k_experts: int = 1,
+                 projection_type: str = "mlp", generalist_idx: int = -1, fusion_method: str = "weighted_average",
+                 cross_attn_heads: int = 8, **kwargs):
+        super().__init__(modality_type="image", hidden_size=hidden_size)
+        self.use_bias_proj = use_bias_proj
+        self.expert_clip_names = list(expert_clip_names or [])
+        self.top_k_experts = top_k_experts
+        self.gating_path = gating_path
+        self.projection_type = projection_type
+        self.image_processor = image_processor
+        self.generalist_idx = generalist_idx
+        self.fusion_method = fusion_method
+        self.cross_attn_heads = cross_attn_heads
+
+
+class MOEImageProcessor(BaseModalityProcessor):
+    """reference image_modality_moe.py:55-88: CLIP preprocessing; the number of placeholder tokens depends on the fusion."""
+
+    def __init__(self, config: MOEImageConfig):
+        super().__init__(config)
+        vis = VisionConfig.from_dict(resolve_vision_config(config.image_processor))
+        self.image_processor = ClipImagePreprocessor(resolve_preprocessor_config(config.image_processor, vis.image_size))
+        self._num_patches_per_entry = vis.num_patches
+        self.top_k_experts = config.top_k_experts
+        self.fusion_method = config.fusion_method
+
+    def process(self, modality: Dict[str, Any]) -> Dict[str, Any]:
+        out = modality.copy()
+        out[MODALITY_VALUE_KEY] = self.image_processor(modality[MODALITY_VALUE_KEY])
+        if self.fusion_method == "sequence_append":
+            out[NUM_EMBEDDINGS_KEY] = self._num_patches_per_entry * self.top_k_experts
+        elif self.fusion_method in ("weighted_average", "cross_attn"):
+            out[NUM_EMBEDDINGS_KEY] = self._num_patches_per_entry
+        else:
+            raise ValueError(f"Unknown fusion_method: {self.fusion_method}")
+        return out
+
+
+class CrossAttention(nn.Module):
+    """reference model/attention.py:5-101 (eval-mode semantics: see the module docstring)."""
+
+    def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = False, attn_drop: float = 0.1, proj_drop: float = 0.1,
+                 dtype=None, device=None):
+        super().__init__()
+        assert dim > 0 and dim % num_heads == 0, "dim must be divisible by num_heads"
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.q_proj = Linear(dim, dim, bias=qkv_bias, dtype=dtype, device=device)
+        self.k_proj = Linear(dim, dim, bias=qkv_bias, dtype=dtype, device=device)
+        self.v_proj = Linear(dim, dim, bias=qkv_bias, dtype=dtype, device=device)
+        self.proj = Linear(dim, dim, dtype=dtype, device=device)
+        self.attn_drop_p, self.proj_drop_p = attn_drop, proj_drop
+        self._wkv = Fm.ParamGroup([self.k_proj.weight, self.v_proj.weight])       # one GEMM for K and V
+        self._bkv = Fm.ParamGroup([self.k_proj.bias, self.v_proj.bias]) if qkv_bias else None
+
+    def forward(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        """x [n, Nq, C] queries, context [n, Nkv, C] (the specialists' tokens, already concatenated along the sequence)."""
+        n, Nq, C = x.shape
+        Nkv = context.shape[1]
+        hw = Fm.attention_head_width(self.head_dim, x.dtype)
+        if hw != self.head_dim:
+            raise ValueError(f"cross-attention head width {self.head_dim} is not tiled by the bf16 attention kernels (64 / 128)")
+        q = self.q_proj(x.reshape(n * Nq, C))
+        kv = Fm.linear(context.reshape(n * Nkv, C), self._wkv, self._bkv, dummy=grad_dummy(self.k_proj.weight))
+        o = Fm.cross_attention(q, kv, n, Nq, Nkv, self.num_heads, self.head_dim, self.scale)
+        return self.proj(o).view(n, Nq, C)
+
+
+@AutoModality.register("moe_meditron_clip")
+class MOEImageModality(BaseModality):
+    config_class = MOEImageConfig
+    preprocessor_class = MOEImageProcessor
+
+    def __init__(self, config: MOEImageConfig, dtype: torch.dtype = torch.bfloat16, device=None,
+                 gating_network: Optional[Callable] = None):
+        super().__init__(config, dtype=dtype)
+        self.expert_names: List[str] = list(config.expert_clip_names)
+        assert len(self.expert_names) > 0, "config.expert_clip_names must be non-empty"
+        self.experts = nn.ModuleList()
+        vis0 = None
+        for name in self.expert_names:
+            vis = VisionConfig.from_dict(resolve_vision_config(name))
+            if vis0 is None:
+                vis0 = vis
+            elif (vis.hidden_size, vis.num_patches) != (vis0.hidden_size, vis0.num_patches):
+                raise ValueError("every expert must produce the same [patches, width] token grid")      # reference :166 comment
+            self.experts.append(VisionTransformer(vis, dtype, device))       # = the reference's `expert_model.vision_model`
+        self.embedding_size = vis0.hidden_size
+        self._num_patches_per_entry = vis0.num_patches
+        self.generalist_idx = config.generalist_idx
+        self.fusion_method = config.fusion_method.replace("-", "_")
+        self.gating_network = gating_network
+        names = list(getattr(getattr(gating_network, "config", None), "class_names", []) or [])
+        if names:                                                        # reference :118-131: gate class order -> expert order
+            lookup = {nm: i for i, nm in enumerate(self.expert_names)}
+            try:
+                perm = [lookup[nm] for nm in names]
+            except KeyError as e:
+                raise ValueError(f"Gating class name {e} not found in expert_clip_names: {self.expert_names}")
+        else:
+            perm = list(range(len(self.experts)))
+        self.register_buffer("_gating_to_expert_perm", torch.tensor(perm, dtype=torch.long), persistent=False)
+        self.projector = MLPProjector(self.embedding_size, config.hidden_size, dtype=dtype, device=device)
+        if self.fusion_method == "cross_attn":
+            self.cross_attn = CrossAttention(self.embedding_size, num_heads=config.cross_attn_heads, qkv_bias=True, dtype=dtype,
+                                             device=device)
+        self.modality_frozen = not self.training
+
+    @property
+    def device(self):
+        return self.experts[0].embeddings.patch_embedding.weight.device
+
+    def gate_weights(self, pixels: torch.Tensor) -> torch.Tensor:
+        if self.gating_network is None:
+            raise NotImplementedError(
+                "MOEImageModality needs a gating network: the reference's GatingNetwork is a torchvision ResNet-50, which is not "
+                "part of this build.  Assign `modality.gating_network = fn` with fn(pixels [n,3,H,W]) -> (logits, topk_indices, "
+                "weights [n, E]) (reference moe/gating.py:73-89).")
+        _logits, _topk, weights = self.gating_network(pixels)
+        w = weights.to(device=self.device, dtype=torch.float32)
+        return w.index_select(-1, self._gating_to_expert_perm.to(w.device)).contiguous()      # reference :171-173, :185-186
+
+    def forward(self, inputs, stages=None) -> torch.Tensor:
+        pixels = torch.stack(list(inputs), dim=0) if not torch.is_tensor(inputs) else inputs
+        pixels = pixels.to(self.device, non_blocking=True)
+        n, E = pixels.shape[0], len(self.experts)
+        w = self.gate_weights(pixels)                                     # [n, E] fp32, expert order
+        feats = []
+        for expert in self.experts:                                       # every expert on every image (reference :156-160)
+            hs = expert(pixels).last_hidden_state                         # [n, 1+P, C]
+            T = hs.shape[1]
+            feats.append(Fm.drop_cls(hs.reshape(n * T, -1), n, T))        # [n, P, C]
+        stacked = torch.stack(feats, dim=0)                               # [E, n, P, C] (device copy; autograd unbinds it)
+        P, C = stacked.shape[2], stacked.shape[3]
+        if self.fusion_method == "sequence_append":
+            fused = stacked.permute(1, 0, 2, 3).reshape(n, E * P, C)
+        elif self.fusion_method == "weighted_average":
+            fused = Fm.expert_fuse(stacked, w, list(range(E)), 0)
+        elif self.fusion_method == "cross_attn":
+            gi = self.generalist_idx % E
+            spec = [i for i in range(E) if i != gi]
+            ctx = Fm.expert_fuse(stacked, w, spec, 1)                     # [n, (E-1)*P, C], each specialist scaled by its weight
+            fused = self.cross_attn(stacked[gi], ctx)
+        else:
+            raise ValueError(f"Unsupported fusion_method: {self.fusion_method}")
+        out = self.projector(fused.contiguous())
+        if stages is not None:
+            stages["moe_fused"] = fused
+            stages["projector_out"] = out
+        return out
+
+    def freeze_modality_embedder(self):
+        for e in self.experts:
+            for p in e.parameters():
+                p.requires_grad = False
+        self.modality_frozen = True
+
+    def unfreeze_modality_embedder(self):
+        for e in self.experts:
+            for p in e.parameters():
+                p.requires_grad = True
+        self.modality_frozen = False
+
+    def unfreeze_projection(self):
+        for p in self.projector.parameters():
+            p.requires_grad = True

@@ -31,6 +31,8 @@ calls at that line -- `HF:` = transformers 5.15.0):
   causal_lm_loss      HF:loss/loss_utils.py:36-71 (shift, CE ignore_index=-100, mean over kept tokens)
   multimodal_forward  model.py:449-526
   greedy_generate     model.py:528-640 (argmax(softmax(logits/T)); decode position = padded length + i - 1)
+  cross_attention     model/attention.py:48-101 (eval mode: dropout off)
+  moe_image_modality  modalities/image_modality_moe.py:152-210 downstream of the gating network (gate weights are an input)
 """
 from __future__ import annotations
 
@@ -69,9 +71,10 @@ def _mha_noncausal(x, w, pre, heads):
     return F.linear(o, w[pre + "out_proj.weight"], w[pre + "out_proj.bias"])
 
 
-def clip_vision_tower(w: Dict[str, torch.Tensor], pixels: torch.Tensor, vis: dict, stages: Optional[dict] = None):
+def clip_vision_tower(w: Dict[str, torch.Tensor], pixels: torch.Tensor, vis: dict, stages: Optional[dict] = None,
+                      prefix: Optional[str] = None):
     """pixels [n,3,H,W] -> last_hidden_state [n,1+P,Dv] (pre post-LN, CLS still present)."""
-    pre = VIS_PREFIX
+    pre = VIS_PREFIX if prefix is None else prefix
     pw = w[pre + "embeddings.patch_embedding.weight"]
     ps = vis["patch_size"]
     patches = F.conv2d(pixels.to(pw.dtype), pw, None, stride=ps)          # [n,Dv,g,g]
@@ -124,8 +127,8 @@ def siglip_vision_tower(w: Dict[str, torch.Tensor], pixels: torch.Tensor, vis: d
     return x
 
 
-def mlp_projector(w, x):
-    p = PROJ_PREFIX
+def mlp_projector(w, x, prefix: Optional[str] = None):
+    p = PROJ_PREFIX if prefix is None else prefix
     x = F.gelu(F.linear(x, w[p + "0.weight"], w[p + "0.bias"]))
     x = F.gelu(F.linear(x, w[p + "2.weight"], w[p + "2.bias"]))
     return F.linear(x, w[p + "4.weight"], w[p + "4.bias"])
@@ -140,6 +143,46 @@ def image_modality(w, pixels, vis, stages=None):
     if stages is not None:
         stages["projector_out"] = out
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# MoE image modality: modalities/image_modality_moe.py:152-210, model/attention.py:48-101
+# ------------------------------------------------------------------------------------------
+def cross_attention(w, pre, x, experts_ctx, heads):
+    """model/attention.py:60-101 in eval mode (attn_drop / proj_drop are identities): queries x [B,Nq,C] attend over the
+    contexts concatenated along the sequence; biased q/k/v projections, softmax(q k^T / sqrt(d)) v, output projection."""
+    B, Nq, C = x.shape
+    ctx = torch.cat(experts_ctx, dim=1)
+    hd = C // heads
+    q = F.linear(x, w[pre + "q_proj.weight"], w.get(pre + "q_proj.bias")).view(B, Nq, heads, hd).transpose(1, 2)
+    k = F.linear(ctx, w[pre + "k_proj.weight"], w.get(pre + "k_proj.bias")).view(B, -1, heads, hd).transpose(1, 2)
+    v = F.linear(ctx, w[pre + "v_proj.weight"], w.get(pre + "v_proj.bias")).view(B, -1, heads, hd).transpose(1, 2)
+    a = torch.softmax(torch.matmul(q, k.transpose(-2, -1)) * (hd ** -0.5), dim=-1)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(B, Nq, C)
+    return F.linear(o, w[pre + "proj.weight"], w[pre + "proj.bias"])
+
+
+def moe_image_modality(w, pixels, gate_weights, vis, num_experts, fusion, generalist_idx=-1, heads=8, perm=None):
+    """image_modality_moe.py:152-210 downstream of the gate: every expert tower on every image (CLS dropped), one of the
+    three fusions, then the MLP projector.  `gate_weights` [n, E] = the gating network's softmax output (the ResNet-50 gate
+    itself is out of scope: torchvision is absent); `perm` maps gate classes to expert order (:118-135)."""
+    outs = [clip_vision_tower(w, pixels, vis, prefix=f"experts.{e}.")[:, 1:, :] for e in range(num_experts)]
+    st = torch.stack(outs, dim=1)                                     # [n, E, P, C]
+    gw = gate_weights if perm is None else gate_weights.index_select(-1, perm)
+    if fusion == "sequence_append":
+        fused = torch.flatten(st, 1, 2)
+    elif fusion == "weighted_average":
+        fused = (st * gw.to(st.dtype)[:, :, None, None]).sum(dim=1)
+    elif fusion == "cross_attn":
+        E = num_experts
+        gi = generalist_idx % E
+        spec = [i for i in range(E) if i != gi]
+        ws = torch.softmax(gw[:, spec], dim=-1).to(st.dtype)
+        ctx = [st[:, e] * ws[:, j].view(-1, 1, 1) for j, e in enumerate(spec)]
+        fused = cross_attention(w, "cross_attn.", st[:, gi], ctx, heads)
+    else:
+        raise ValueError(f"Unsupported fusion_method: {fusion}")
+    return mlp_projector(w, fused, prefix="projector.projection.")
 
 
 # ------------------------------------------------------------------------------------------

@@ -441,6 +441,99 @@ def siglip_fixture(name="tiny_siglip_qwen2", seed=300):
             json.dump(meta, f, indent=1, sort_keys=True, default=str)
         print(name, "weights", sum(v.numel() for v in w.values()), "vector tensors", len(out))
 
+
+# ---- MoE image modality -------------------------------------------------------------
+# reference modalities/image_modality_moe.py:152-210: E CLIP vision towers + a gating network + one of three fusions
+# (sequence_append / weighted_average / cross_attn over model/attention.py:48-101) + the MLP projector.  The gate is a
+# torchvision ResNet-50 (absent here: its arithmetic stays "parity unpinned"); the harness plugs a stub with the gate's
+# OUTPUT CONTRACT (logits, top-k indices, softmax weights) so that everything downstream of the gate is pinned:
+#     weights = softmax(mean_hw(pixels) @ Wg^T + bg)
+def moe_fixture(name="tiny_moe_clip", seed=500):
+    import multimeditron.model.modalities.image_modality_moe as moe
+    moe.AutoImageProcessor = types.SimpleNamespace(from_pretrained=CLIPImageProcessorPil.from_pretrained)
+    E = 3
+
+    class StubGate(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(seed + 5)
+            self.w = torch.nn.Parameter(bf16_round_(torch.randn(E, 3, generator=g)))
+            self.b = torch.nn.Parameter(bf16_round_(0.3 * torch.randn(E, generator=g)))
+            self.config = types.SimpleNamespace(class_names=[])
+
+        def forward(self, px):
+            logits = px.float().mean(dim=(2, 3)) @ self.w.t() + self.b
+            return logits, logits.topk(1, dim=-1).indices, torch.softmax(logits, dim=-1)
+
+    moe.GatingNetwork = types.SimpleNamespace(from_pretrained=lambda path: StubGate())
+    out, weights = {}, None
+    with tempfile.TemporaryDirectory() as tmp:
+        dirs = []
+        for e in range(E):
+            d = os.path.join(tmp, f"clip{e}")
+            os.makedirs(d)
+            make_clip_dir(d, seed + 10 * e)
+            dirs.append(d)
+        g = torch.Generator().manual_seed(seed + 1)
+        n = 3
+        pixels = [bf16_round_(torch.randn(3, VIS["image_size"], VIS["image_size"], generator=g)) for _ in range(n)]
+        for fusion in ("weighted_average", "sequence_append", "cross_attn"):
+            torch.manual_seed(seed + 7)
+            cfg = moe.MOEImageConfig(hidden_size=128, expert_clip_names=dirs, image_processor=dirs[0], gating_path="stub",
+                                     top_k_experts=E, generalist_idx=E - 1, fusion_method=fusion, cross_attn_heads=2)
+            m = moe.MOEImageModality(cfg).float()
+            import zlib
+            with torch.no_grad():
+                for nme, q in sorted(m.named_parameters()):
+                    if nme.startswith("gating_network."):
+                        continue
+                    gi = torch.Generator().manual_seed(seed + zlib.crc32(nme.encode()) % 100003)   # per name: every fusion variant
+                                                                                                    # gets the same shared weights
+                    if "layer_norm" in nme or "layrnorm" in nme:
+                        q.copy_((1.0 if nme.endswith("weight") else 0.0) + 0.1 * torch.randn(q.shape, generator=gi))
+                    elif q.ndim == 1:
+                        q.copy_(0.1 * torch.randn(q.shape, generator=gi))
+                    else:
+                        q.copy_(0.06 * torch.randn(q.shape, generator=gi))
+                    bf16_round_(q)
+            m.eval()                                           # dropout (attn_drop / proj_drop 0.1) off: no RNG in the fixture
+            for q in m.parameters():
+                q.requires_grad_(True)
+            y = m(pixels)
+            G = bf16_round_(torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 13)))
+            (y * G).sum().backward()
+            out[f"{fusion}.out"] = y.detach().float().clone()
+            out[f"{fusion}.dout"] = G
+            for nme, q in m.named_parameters():
+                if q.grad is not None and not nme.startswith("gating_network.") and (
+                        "projector" in nme or "cross_attn" in nme or "experts.0.encoder.layers.1" in nme or "experts.2.embeddings" in nme
+                        or "experts.1.encoder.layers.0.mlp" in nme):
+                    out[f"{fusion}.grad.{nme}"] = q.grad.detach().float().clone()
+            with torch.no_grad():
+                _, _, gw = m.gating_network(torch.stack(pixels))
+            out[f"{fusion}.gate_weights"] = gw.float().clone()
+            sd = {k: v.detach().to(torch.bfloat16).contiguous().clone() for k, v in m.state_dict().items()
+                  if not k.startswith("gating_network.") and "position_ids" not in k and "post_layernorm" not in k
+                  and not k.startswith("_gating")}
+            if weights is None:
+                weights = {}
+            for k, v in sd.items():        # cross_attn.* exists only in the cross_attn variant; the rest is shared
+                if k in weights:
+                    assert torch.equal(weights[k], v), k
+                weights[k] = v
+        out["pixels"] = torch.stack(pixels)
+        gate = StubGate()
+        out["gate.w"], out["gate.b"] = gate.w.detach().clone(), gate.b.detach().clone()
+    save_file(weights, os.path.join(OUT, f"{name}.weights.safetensors"))
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(OUT, f"{name}.vectors.safetensors"))
+    with open(os.path.join(OUT, f"{name}.meta.json"), "w") as f:
+        json.dump(dict(name=name, vision=VIS, num_experts=E, generalist_idx=E - 1, cross_attn_heads=2, hidden_size=128,
+                       fusions=["weighted_average", "sequence_append", "cross_attn"], transformers=transformers.__version__,
+                       torch=torch.__version__,
+                       note="reference MOEImageModality in eval mode (dropout off) with a stub gate standing for the torchvision "
+                            "ResNet-50 GatingNetwork: weights = softmax(mean_hw(pixels) @ Wg^T + bg)"), f, indent=1, sort_keys=True)
+    print(name, "weights", sum(v.numel() for v in weights.values()), "vector tensors", len(out))
+
 # ---- collator fixture ------------------------------------------------------------------------
 LLAMA3_TEMPLATE = (
     "{% for message in messages %}"
@@ -559,7 +652,7 @@ def collator_fixture():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["llama", "qwen2", "llama_d128", "siglip", "collator"]
+    which = sys.argv[1:] or ["llama", "qwen2", "llama_d128", "siglip", "moe", "collator"]
     if "llama" in which:
         model_fixture("tiny_clip_llama", llama_cfg(), 100)
     if "qwen2" in which:
@@ -568,5 +661,7 @@ if __name__ == "__main__":
         model_fixture("tiny_clip_llama_d128", llama_d128_cfg(), 400, long_seq=True)
     if "siglip" in which:
         siglip_fixture()
+    if "moe" in which:
+        moe_fixture()
     if "collator" in which:
         collator_fixture()
