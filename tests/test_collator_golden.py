@@ -99,3 +99,26 @@ def test_errors_match_reference_behaviour(env):
         FileSystemImageLoader(imgdir).load({"value": "missing.jpg"})
     with pytest.raises(ValueError):
         ChatTemplate.from_name("nope")
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_2d_position_ids_branch(env, side, tmp_path):
+    """reference data_loader.py:159-188 + image_modality.py:99-108: with use_2d_position_ids the collator emits [B, S, 2]
+    position ids (row/column grid inside an image span, later text shifted by the span's 2-D extent).  Bit-exact vs the
+    reference collator's output (no supported LLM consumes these ids, the branch is pinned all the same)."""
+    meta, vec, make_tok, proc, ct, imgdir = env
+    d = tmp_path / "clip2d"
+    os.makedirs(d)
+    json.dump({"vision_config": {"hidden_size": 128, "intermediate_size": 256, "num_hidden_layers": 2, "num_attention_heads": 2,
+                                 "image_size": meta["image_size"], "patch_size": meta["patch_size"]}}, open(d / "config.json", "w"))
+    json.dump({"size": {"shortest_edge": meta["image_size"]}, "crop_size": {"height": meta["image_size"], "width": meta["image_size"]}},
+              open(d / "preprocessor_config.json", "w"))
+    proc2d = AutoModality.preprocessor_from_name("meditron_clip", ImageConfig(hidden_size=128, clip_name=str(d), use_2d_position_ids=True))
+    coll = DataCollatorForMultimodal(tokenizer=make_tok(side), modality_processors={"image": proc2d},
+                                     modality_loaders={"image": AutoModalityLoader.from_name("fs-image", base_path=imgdir)},
+                                     attachment_token=meta["attachment_token"], chat_template=ct, use_2d_position_ids=True)
+    b = coll(copy.deepcopy(meta["samples_conv"]))
+    tag = f"pos2d_{side}"
+    assert b["position_ids"].shape == vec[f"{tag}.position_ids"].shape and b["position_ids"].dim() == 3
+    for k in ("input_ids", "attention_mask", "position_ids"):
+        assert torch.equal(b[k], vec[f"{tag}.{k}"]), k

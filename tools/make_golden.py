@@ -609,6 +609,23 @@ def collator_fixture():
                 out[f"{tag}.token_range"] = b["processed_multimodal_inputs"]["token_range"]["image"].clone()
                 out[f"{tag}.pixels"] = torch.stack(b["processed_multimodal_inputs"]["stacked"]["image"]).clone()
                 meta["cases"][tag] = {"padding_side": side, "add_generation_prompt": gen, "kind": "conversations"}
+        # 2-D position ids (data_loader.py:159-188 + image_modality.py:99-108): [B, S, 2]; no supported LLM consumes them, the
+        # collator branch is pinned all the same
+        proc2d = im.ImageProcessor(ImageConfig(hidden_size=128, clip_name=tmp, use_2d_position_ids=True))
+        for side in ("right", "left"):
+            tok = make_tokenizer()
+            tok.padding_side = side
+            coll = DataCollatorForMultimodal(tokenizer=tok, modality_processors={"image": proc2d},
+                                             modality_loaders={"image": FileSystemImageLoader("/root/reference/mock_dataset")},
+                                             attachment_token="<|attachment|>", chat_template=llama_spaced_template(),
+                                             use_2d_position_ids=True)
+            import copy
+            b = coll(copy.deepcopy(samples_conv))
+            tag = f"pos2d_{side}"
+            for k in ("input_ids", "attention_mask", "position_ids"):
+                out[f"{tag}.{k}"] = b[k].clone()
+            assert out[f"{tag}.position_ids"].dim() == 3
+            meta["cases"][tag] = {"padding_side": side, "kind": "conversations", "use_2d_position_ids": True}
         # text samples through the raw-image (bytes) loader
         tok = make_tokenizer()
         tok.padding_side = "right"
