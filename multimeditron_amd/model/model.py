@@ -162,18 +162,26 @@ class MultiModalModelForCausalLM(nn.Module):
                     p.normal_(mean=0.0, std=std)
 
     def _component_params(self):
+        """(name, parameter, component, weight_decay) for every parameter; weight_decay follows HF Trainer's grouping."""
+        from ..nn import hf_decays
+        owner = {}
+        for mod in self.modules():
+            for p in mod._parameters.values():
+                if p is not None:
+                    owner.setdefault(id(p), mod)
         seen, out = set(), []
         for n, p in self.model.named_parameters():
             if id(p) not in seen:
                 seen.add(id(p))
-                out.append(("model." + n, p, "llm"))
+                out.append(("model." + n, p, "llm", hf_decays("model." + n, owner.get(id(p)))))
         for i, m in enumerate(self.modalities_with_projection):
             for n, p in m.named_parameters():
                 if id(p) in seen:
                     continue
                 seen.add(id(p))
                 comp = f"projector{i}" if n.startswith("projector.") else f"encoder{i}"
-                out.append((f"modalities_with_projection.{i}.{n}", p, comp))
+                full = f"modalities_with_projection.{i}.{n}"
+                out.append((full, p, comp, hf_decays(full, owner.get(id(p)))))
         return out
 
     def pack_parameters(self) -> FlatParams:

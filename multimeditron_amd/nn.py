@@ -64,6 +64,24 @@ class Norm(nn.Module):
         return Fm.layernorm(x2d, self.weight, self.bias, self.eps, dummy=d)
 
 
+_HF_NO_DECAY = None
+
+
+def hf_decays(name: str, owner: nn.Module) -> bool:
+    """Does HF Trainer apply weight decay to this parameter?  `Trainer.get_decay_parameter_names` (transformers 5.15): every
+    parameter EXCEPT those of nn.LayerNorm modules and those whose lower-cased name matches bias | layernorm | rmsnorm |
+    (^|.)norm($|.) | _norm($|.).  `Norm` stands where HF has nn.LayerNorm / LlamaRMSNorm.  Note what this DOES decay:
+    CLIP's 1-D `class_embedding`, the position embeddings, the patch convolution (tests/test_schedule_cpu.py)."""
+    import re
+    global _HF_NO_DECAY
+    if _HF_NO_DECAY is None:
+        _HF_NO_DECAY = [re.compile(p) for p in (r"bias", r"layernorm", r"rmsnorm", r"(?:^|\.)norm(?:$|\.)", r"_norm(?:$|\.)")]
+    if isinstance(owner, Norm):
+        return False
+    low = name.lower()
+    return not any(p.search(low) for p in _HF_NO_DECAY)
+
+
 _dummies: Dict[str, torch.Tensor] = {}
 
 
@@ -91,18 +109,20 @@ class FlatSegment:
 class FlatParams:
     """Flat parameter + gradient storage for one model (single dtype)."""
 
-    def __init__(self, named_params: List[Tuple[str, nn.Parameter, str]], device, dtype):
-        # order: per component, matrices (decayed) first, then vectors (not decayed); fused groups stay adjacent
-        # because they are adjacent in module order.
+    def __init__(self, named_params, device, dtype):
+        """named_params: (name, parameter, component[, weight_decay]) tuples.  Without the 4th element a parameter is decayed
+        iff it has >= 2 dimensions; MultiModalModelForCausalLM passes HF Trainer's rule (`hf_decays`)."""
+        # order: per component, the weight-decayed parameters first, then the others; fused groups (q/k/v, gate/up weights,
+        # their biases) stay adjacent because they are adjacent in module order and share their decay flag.
+        items = [(t[0], t[1], t[2], (t[3] if len(t) > 3 else t[1].dim() >= 2)) for t in named_params]
         ordered = []
         comps = []
-        for _, _, c in named_params:
+        for _, _, c, _ in items:
             if c not in comps:
                 comps.append(c)
         for c in comps:
-            mats = [(n, p) for n, p, cc in named_params if cc == c and p.dim() >= 2]
-            vecs = [(n, p) for n, p, cc in named_params if cc == c and p.dim() < 2]
-            ordered += [(n, p, c, True) for n, p in mats] + [(n, p, c, False) for n, p in vecs]
+            ordered += [(n, p, c, True) for n, p, cc, d in items if cc == c and d]
+            ordered += [(n, p, c, False) for n, p, cc, d in items if cc == c and not d]
         off = 0
         self.segments: List[FlatSegment] = []
         for n, p, c, decay in ordered:

@@ -38,12 +38,19 @@ TRAINING_MAPPING = {i.name: i for i in TrainingMode}
 
 
 def cosine_with_min_lr(step: int, total: int, base_lr: float, min_lr: float, warmup: int = 0) -> float:
+    """Learning rate of optimiser step `step` (0 = the first) under HF's `lr_scheduler_type: cosine_with_min_lr` with
+    `lr_scheduler_kwargs: {min_lr}` (reference config/config_alignment.yaml:54-56 -> HF:optimization.py
+    _get_cosine_schedule_with_warmup_lr_lambda, num_cycles = 0.5): linear warm-up from 0, then
+    lr = base * (f * (1 - r) + r), f = (1 + cos(pi * progress)) / 2, r = min_lr / base.  tests/test_schedule_cpu.py holds it to
+    HF's scheduler step by step."""
     if total <= 0:
         return base_lr
     if step < warmup:
-        return base_lr * (step + 1) / max(1, warmup)
-    prog = min(1.0, (step - warmup) / max(1, total - warmup))
-    return min_lr + (base_lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * prog))
+        return base_lr * float(step) / float(max(1, warmup))
+    progress = float(step - warmup) / float(max(1, total - warmup))
+    factor = 0.5 * (1.0 + math.cos(math.pi * progress))
+    rate = min_lr / base_lr if base_lr else 0.0
+    return base_lr * max(0.0, factor * (1.0 - rate) + rate)
 
 
 class MultimodalTrainer:

@@ -1,0 +1,57 @@
+"""Optimiser recipe details against HF transformers itself (the reference trains through HF Trainer:
+config/config_alignment.yaml:38-59): the `cosine_with_min_lr` schedule step by step, and which parameters get weight decay
+(`Trainer.get_decay_parameter_names`)."""
+import re
+
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests.model_utils import build_from_golden
+
+
+@pytest.mark.parametrize("warmup,total", [(0, 20), (3, 20), (5, 7), (0, 1)])
+def test_cosine_with_min_lr_equals_hf_scheduler(warmup, total):
+    from transformers.optimization import get_scheduler
+    from multimeditron_amd.train.trainer import cosine_with_min_lr
+    base, mn = 1e-4, 3e-5
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=base)
+    sch = get_scheduler("cosine_with_min_lr", optimizer=opt, num_warmup_steps=warmup, num_training_steps=total,
+                        scheduler_specific_kwargs={"min_lr": mn})
+    for step in range(total + 3):
+        hf = opt.param_groups[0]["lr"]                      # the rate HF applies at optimiser step `step`
+        ours = cosine_with_min_lr(step, total, base, mn, warmup)
+        assert abs(hf - ours) <= 1e-12 + 1e-9 * abs(hf), (step, hf, ours)
+        opt.step()
+        sch.step()
+
+
+def test_weight_decay_grouping_equals_hf_trainer(golden_dir, tmp_path):
+    """HF decays everything except LayerNorm-module parameters and names matching bias|layernorm|rmsnorm|.norm.|_norm: so
+    CLIP's 1-D class_embedding IS decayed (it was not).  Checked against HF's own function on HF modules of the
+    same structure (CLIPVisionModel / LlamaForCausalLM built from the fixture's config)."""
+    import torch.nn as nn
+    from transformers import CLIPVisionConfig, CLIPVisionModel, LlamaConfig, LlamaForCausalLM
+    from transformers.trainer_pt_utils import get_parameter_names
+    meta, w, v = R.load_golden("tiny_clip_llama", golden_dir)
+    m = build_from_golden(meta, w, tmp_path, "float32", device="cpu")
+    flat = m.flat_params()
+    ours = {sg.name for sg in flat.segments if sg.decay}
+    patterns = [r"bias", r"layernorm", r"rmsnorm", r"(?:^|\.)norm(?:$|\.)", r"_norm(?:$|\.)"]
+    vis_cfg = {k: meta["vision"][k] for k in ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                                                "image_size", "patch_size")}
+    hf_vis = CLIPVisionModel(CLIPVisionConfig(**vis_cfg))
+    llm_cfg = {k: val for k, val in meta["llm"].items() if k in ("hidden_size", "intermediate_size", "num_hidden_layers",
+                                                                  "num_attention_heads", "num_key_value_heads", "head_dim", "vocab_size")}
+    hf_llm = LlamaForCausalLM(LlamaConfig(**llm_cfg))
+    # transformers 5.x CLIPVisionModel holds the tower's modules directly; the reference keeps a CLIPModel (`.vision_model.`)
+    want = {"modalities_with_projection.0.feature_extractor.vision_model." + n.removeprefix("vision_model.")
+            for n in get_parameter_names(hf_vis, [nn.LayerNorm], patterns) if "post_layernorm" not in n}
+    want |= {"model." + n for n in get_parameter_names(hf_llm, [nn.LayerNorm], patterns)}
+    want |= {n for n in dict(m.named_parameters()) if ".projector." in n and n.endswith("weight")}
+    own = set(dict(m.named_parameters()))
+    assert want <= own, sorted(want - own)[:5]
+    assert ours == want, (sorted(ours - want)[:5], sorted(want - ours)[:5])
+    assert "modalities_with_projection.0.feature_extractor.vision_model.embeddings.class_embedding" in ours
+    assert not any(re.search(r"bias|norm", n.lower()) for n in ours)
