@@ -939,6 +939,211 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_fwd128_kernel(AttnArgs a) {
   }
 }
 
+// ---- D = 128 forward, 8 waves, fragments PREFETCHED --------------------------------------------------------------------
+// rocprofv3 on attn_fwd128_kernel: MFMA busy 30 %, and halving its VALU count changed nothing.  The ISA showed why: at 246+
+// VGPRs hipcc keeps ONE register quad for the K fragments, so the QK^T phase is `ds_read_b128 -> s_waitcnt lgkmcnt(0) ->
+// v_mfma` sixteen times over: every MFMA (32 cycles) waits out a whole LDS round trip (>100 cycles), and the wave's partner on
+// the SIMD is in the same phase.  This kernel (same tile, same arithmetic and rounding points, bit-identical results) fixes
+// the two causes:
+//   * LDS image (a) of the guide (8-row x 64-byte subtiles): every fragment address is a per-lane base + a CONSTANT, so the
+//     16 K row reads hang off 2 base registers and the 32 V^T transposed reads off 2 more (was 8 + 8 registers and an
+//     address add per read), and the DMA source offsets are 2 lane patterns + scalars (was 8 registers);
+//   * the freed registers hold a 3-deep fragment ring: fragment i+2 is requested before MFMA i is issued, and
+//     `sched_barrier(0)` between the (read, MFMA) chunks keeps hipcc from collapsing the ring again.
+__device__ __forceinline__ int imga_off(int row, int ch) {      // byte offset of 16-byte chunk ch of row `row` in a 256-B-row tile
+  return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+struct ImgaBases { const char* kr[2]; const char* vt[2]; };     // per-lane bases inside stage 0 (K tile at 0, V tile at `tile_bytes`)
+__device__ __forceinline__ ImgaBases imga_bases(const char* smem, int tile_bytes) {
+  const int l = threadIdx.x & 63, h = l >> 5, r = l & 31;
+  ImgaBases B;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)          // row fragment of k-step ds (32x32x16 A operand): row r, chunk 2*ds + h; a = ds & 1
+    B.kr[a] = smem + 2048 * (r >> 3) + 64 * (r & 7) + 16 * ((2 * a + h) ^ ((r >> 2) & 3));
+  const int gi = (l >> 4) & 1, i = l & 15, q = i >> 2, p = i & 3;
+  const int cl = gi * 2 + (p >> 1);    // chunk inside the 64-byte d block; rows kbase + 4h + q (first read) and + 8 (second)
+  B.vt[0] = smem + tile_bytes + 64 * (4 * h + q) + 16 * (cl ^ h) + 8 * (p & 1);
+  B.vt[1] = smem + tile_bytes + 2048 + 64 * (4 * h + q) + 16 * (cl ^ (h ^ 2)) + 8 * (p & 1);
+  return B;
+}
+__device__ __forceinline__ bf16x8 imga_kfrag(const ImgaBases& B, int stage_off, int kb, int ds) {
+  return *(const bf16x8*)(B.kr[ds & 1] + stage_off + 8192 * kb + 512 * (ds >> 1));
+}
+__device__ __forceinline__ bf16x8 imga_vfrag(const ImgaBases& B, int stage_off, int db, int kbase16) {   // kbase16 = first key / 16
+  const int off = stage_off + 4096 * kbase16 + 512 * db;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, B.vt[0] + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, B.vt[1] + off));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+
+// K and V tiles (64 rows x 256 B each) of key tile t into stage `st` (LDS byte address), image (a), issued by waves 0-3:
+// wave w moves pieces 4w .. 4w+3 of each tile; lk / lv = the two per-lane source patterns (see attn_fwd128p_kernel)
+__device__ __forceinline__ void imga_lane_patterns(unsigned (&lk)[2], unsigned (&lv)[2], int64_t k_ss, int64_t v_ss) {
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int rl = (l >> 2) & 7, cl = 4 * (l >> 5) + ((l & 3) ^ ((s2 << 1) | ((l >> 4) & 1)));
+    lk[s2] = (unsigned)((int64_t)rl * k_ss * 2 + cl * 16);
+    lv[s2] = (unsigned)((int64_t)rl * v_ss * 2 + cl * 16);
+  }
+}
+__device__ __forceinline__ void imga_issue_kv(int w, unsigned st, int row0, const SRsrc& rk, const SRsrc& rv, const unsigned (&lk)[2],
+                                              const unsigned (&lv)[2], int64_t k_ss, int64_t v_ss, int tile_bytes) {
+  if (w >= 4) return;
+  st += (unsigned)w * 4096u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int prow = row0 + 8 * (2 * w + (i >> 1));                 // first row of the piece (wave-uniform)
+    lds_dma16(rk, lk[i >> 1] + (unsigned)((int64_t)prow * k_ss * 2 + (i & 1) * 128), st + i * 1024);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int prow = row0 + 8 * (2 * w + (i >> 1));
+    lds_dma16(rv, lv[i >> 1] + (unsigned)((int64_t)prow * v_ss * 2 + (i & 1) * 128), st + tile_bytes + i * 1024);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fwd128p_kernel(AttnArgs a) {
+  constexpr int QB = 256, BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
+  const int l = threadIdx.x & 63, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int qblk, b, hq;
+  attn_work_item(blockIdx.x, (a.Sq + QB - 1) / QB, a.B, a.Hq, a.Hkv, a.causal != 0, qblk, b, hq);
+  const int hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = qblk * QB + w * 32;
+  const int qi = q0 + (l & 31);
+  const int shift = a.Skv - a.Sq;
+  const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
+  const SRsrc rk = rows_rsrc((const bf16*)a.k + b * a.k_sb + hkv * a.k_sh, a.Skv, a.k_ss);
+  const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const ImgaBases bases = imga_bases(smem, TILE);
+
+  bf16x8 qf[NDS];
+  {
+    const bf16* qrow = qi < a.Sq ? Q + (int64_t)qi * a.q_ss : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) qf[ds] = row_frag_global(qrow, ds);
+  }
+  f32x16 o_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc = a.scale * LOG2E;
+
+  int ntiles = (a.Skv + BKV - 1) / BKV;
+  if (a.causal) {
+    const int qmax = min(a.Sq - 1, qblk * QB + QB - 1) + shift;
+    ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
+  }
+  // DMA: waves 0-3 issue (staggers the two waves of every SIMD); wave w moves pieces 4w .. 4w+3 of each 16-piece tile.  Piece
+  // pc = 8 rows x 128 B: lane l reads row 8*(pc>>1) + ((l>>2)&7), chunk 8*(pc&1) + 4*(l>>5) + ((l&3) ^ (2*((pc>>1)&1) | (l>>4)&1)),
+  // i.e. one of TWO lane patterns (pieces 4w, 4w+1 -> s = 0; 4w+2, 4w+3 -> s = 1) plus a wave-uniform offset.
+  unsigned lk[2], lv[2];
+  imga_lane_patterns(lk, lv, a.k_ss, a.v_ss);
+  auto issue = [&](int t) {
+    imga_issue_kv(w, lds0 + (unsigned)((t & 1) * 2 * TILE), t * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
+  };
+  if (ntiles > 0) issue(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * BKV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < ntiles) issue(t + 1);
+    // wave-uniform skip: this wave's rows are all beyond Sq, or the whole tile lies above its causal diagonal
+    if (q0 >= a.Sq || (a.causal && kv0 > q0 + 31 + shift)) continue;
+    const int so = (t & 1) * 2 * TILE;
+    bool kvalid = (kv0 + l) < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + kv0 + l] != 0;
+    const unsigned long long kbits = __ballot(kvalid);
+    const bool need_mask = (kbits != ~0ull) || (a.causal && (kv0 + BKV - 1) > (q0 + shift));
+
+    // ---- S^T = K . Q^T: 16 MFMAs, K fragment i+2 requested before MFMA i
+    f32x16 s_acc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.f;
+    constexpr int RD = 4;                                            // fragment ring depth: RD - 1 fragments in flight
+    bf16x8 kf[RD];
+#pragma unroll
+    for (int j = 0; j < RD - 1; ++j) kf[j] = imga_kfrag(bases, so, 0, j);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i + RD - 1 < 16) kf[(i + RD - 1) % RD] = imga_kfrag(bases, so, (i + RD - 1) >> 3, (i + RD - 1) & 7);
+      s_acc[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RD], qf[i & 7], s_acc[i >> 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    bf16x8 vf[RD];                                                   // first V^T fragments travel under the softmax
+#pragma unroll
+    for (int j = 0; j < RD - 1; ++j) vf[j] = imga_vfrag(bases, so, j >> 2, j & 3);
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kl = kb * 32 + acc_row(r, h);
+          bool ok = (kbits >> kl) & 1ull;
+          if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
+          s_acc[kb][r] = ok ? s_acc[kb][r] : -INFINITY;
+        }
+    }
+    const float mx = swap32_max(rowmax32(s_acc[0], s_acc[1])) * sc;
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    float rs = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], sc, -m_safe));
+        rs += p;
+        pf[kb][r >> 3][r & 7] = (bf16)p;
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T . P^T: 16 MFMAs (d block db, key step ks = 16 keys), V^T fragment i+2 requested before MFMA i
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                                   // i = db * 4 + ks
+      if (i + RD - 1 < 16) vf[(i + RD - 1) % RD] = imga_vfrag(bases, so, (i + RD - 1) >> 2, (i + RD - 1) & 3);
+      o_acc[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % RD], pf[(i >> 1) & 1][i & 1], o_acc[i >> 2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  const float l_tot = swap32_sum(l_run);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qi < a.Sq) {
+    bf16* orow = (bf16*)a.out + (((int64_t)b * a.Sq + qi) * a.Hq + hq) * 128;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(o_acc[db][rg * 4 + e] * inv);
+        *(bf16x4*)(orow + db * 32 + 8 * rg + 4 * h) = o;
+      }
+    if (h == 0) a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : INFINITY;
+  }
+}
+
 // dK/dV for D = 128: 4 waves x 32 keys, TWO workgroups per CU.  Register diet that makes 2 waves/SIMD fit: V fragments
 // come from an LDS image of the workgroup's 128 keys (not registers) and the Q / dO tiles arrive by LDS-DMA (no staging
 // registers) into a 2-deep ring, one barrier per query tile.
@@ -1243,6 +1448,141 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pair_kernel(AttnArgs a
   }
 }
 
+// dQ for D = 128 with prefetched fragments (same treatment as attn_fwd128p_kernel: image (a), base + constant addressing, a
+// 4-deep fragment ring; same arithmetic and rounding as attn_bwd_dq128_kernel, bit-identical results).  Per 32-key step the
+// wave reads 16 row fragments (K for S^T = K.Q^T, V for dP^T = V.dO^T) and 8 transposed K fragments (dQ^T += K^T.dS^T) -- all
+// 24 are one ring sequence, so the transposed fragments travel under the exponentials.
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq128p_kernel(AttnArgs a) {
+  constexpr int BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
+  const int l = threadIdx.x & 63, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int qblk, b, hq;
+  attn_work_item(blockIdx.x, (a.Sq + 255) / 256, a.B, a.Hq, a.Hkv, a.causal != 0, qblk, b, hq);
+  const int hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = qblk * 256 + w * 32;
+  const int qi = q0 + (l & 31);
+  const int shift = a.Skv - a.Sq;
+  const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
+  const bf16* dO = (const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128;
+  const SRsrc rk = rows_rsrc((const bf16*)a.k + b * a.k_sb + hkv * a.k_sh, a.Skv, a.k_ss);
+  const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const ImgaBases bases = imga_bases(smem, 0);                   // kr: row fragments, vt: transposed fragments, both from tile offset 0
+
+  bf16x8 qf[NDS], dof[NDS];
+  {
+    const bf16* qrow = qi < a.Sq ? Q + (int64_t)qi * a.q_ss : nullptr;
+    const bf16* drow = qi < a.Sq ? dO + (int64_t)qi * a.Hq * 128 : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+      qf[ds] = row_frag_global(qrow, ds);
+      dof[ds] = row_frag_global(drow, ds);
+    }
+  }
+  const float sc = a.scale * LOG2E;
+  float lse2 = INFINITY, dlt = 0.f;
+  if (qi < a.Sq) {
+    lse2 = a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] * LOG2E;
+    dlt = a.delta[((int64_t)b * a.Hq + hq) * a.Sq + qi];
+  }
+  f32x16 dq_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq_acc[i][r] = 0.f;
+
+  int ntiles = (a.Skv + BKV - 1) / BKV;
+  if (a.causal) {
+    const int qmax = min(a.Sq - 1, qblk * 256 + 255) + shift;
+    ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
+  }
+  unsigned lk[2], lv[2];
+  imga_lane_patterns(lk, lv, a.k_ss, a.v_ss);
+  if (ntiles > 0) imga_issue_kv(w, lds0, 0, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * BKV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < ntiles) imga_issue_kv(w, lds0 + (unsigned)(((t + 1) & 1) * 2 * TILE), (t + 1) * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
+    if (q0 >= a.Sq || (a.causal && kv0 > q0 + 31 + shift)) continue;
+    const int so = (t & 1) * 2 * TILE;
+    bool kvalid = (kv0 + l) < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + kv0 + l] != 0;
+    const unsigned long long kbits = __ballot(kvalid);
+    const bool need_mask = (kbits != ~0ull) || (a.causal && (kv0 + BKV - 1) > (q0 + shift));
+    // fragment j of the 24 a 32-key step uses: j < 16: row fragment (j even: K, odd: V) of k-step j >> 1; j >= 16: transposed
+    // K fragment of d block (j - 16) >> 1, 16-key step (j - 16) & 1.  The two 32-key steps of a tile are a ROLLED loop (the
+    // step's LDS offset is folded into four base registers): unrolled, the kernel spilt 34 registers into the tile loop.
+    constexpr int RD = 4;
+#pragma unroll 1
+    for (int kb = 0; kb < 2; ++kb) {
+      const char* kr0 = bases.kr[0] + so + 8192 * kb;
+      const char* kr1 = bases.kr[1] + so + 8192 * kb;
+      const char* vt0 = bases.vt[0] + so + 8192 * kb;
+      const char* vt1 = bases.vt[1] + so + 8192 * kb;
+      auto frag = [&](int j) -> bf16x8 {
+        if (j < 16) return *(const bf16x8*)(((j >> 1) & 1 ? kr1 : kr0) + (j & 1) * TILE + 512 * (j >> 2));
+        const int off = 4096 * ((j - 16) & 1) + 512 * ((j - 16) >> 1);
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, vt0 + off));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, vt1 + off));
+        bf16x8 o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+        return o;
+      };
+      f32x16 s_acc, dp_acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+      bf16x8 fr[RD];
+#pragma unroll
+      for (int j = 0; j < RD - 1; ++j) fr[j] = frag(j);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        fr[(j + RD - 1) % RD] = frag(j + RD - 1);
+        if (j & 1) dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j % RD], dof[j >> 1], dp_acc, 0, 0, 0);
+        else s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j % RD], qf[j >> 1], s_acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      bf16x8 dsf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], sc, -lse2));
+        if (need_mask) {
+          const int kl = kb * 32 + acc_row(r, h);
+          bool ok = (kbits >> kl) & 1ull;
+          if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
+          p = ok ? p : 0.f;
+        }
+        dsf[r >> 3][r & 7] = (bf16)(p * (dp_acc[r] - dlt) * a.scale);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 16; j < 24; ++j) {
+        if (j + RD - 1 < 24) fr[(j + RD - 1) % RD] = frag(j + RD - 1);
+        dq_acc[(j - 16) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j % RD], dsf[(j - 16) & 1], dq_acc[(j - 16) >> 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  if (qi < a.Sq) {
+    bf16* drow = (bf16*)a.dq + b * a.q_sb + hq * a.q_sh + (int64_t)qi * a.q_ss;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)dq_acc[db][rg * 4 + e];
+        *(bf16x4*)(drow + db * 32 + 8 * rg + 4 * h) = o;
+      }
+  }
+}
+
 // dQ for D = 128: same shape as the forward fast path (8 waves, 256 query rows, K/V tiles by LDS-DMA, one barrier per
 // tile).  The single K image serves the row fragments of S^T = K.Q^T and the transposed fragments of dQ^T += K^T.dS^T.
 template <int INW>
@@ -1515,6 +1855,7 @@ __global__ void attn_decode_merge_kernel(const float* ws, int nsplit, bf16* out)
 }
 
 int g_attn_fwd_waves = 8;     // waves per workgroup of the D=128 forward (mm_set_option "attn_fwd_waves": 8 or 4)
+int g_attn_fwd_pf = 1;        // D=128 forward with prefetched fragments (attn_fwd128p_kernel; mm_set_option "attn_fwd_pf" 0 = the older kernel)
 int g_attn_dkv_pair = 1;      // balanced paired dK/dV kernel (mm_set_option "attn_dkv_pair"; 0 = one key block per workgroup)
 int g_attn_issue_waves = 4;   // waves issuing the K/V DMA in the 8-wave D=128 kernels (mm_set_option "attn_issue_waves")
 
@@ -1525,6 +1866,14 @@ static bool attn_use_v1() {
 
 template <int D>
 int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
+  if (D == 128 && !attn_use_v1() && g_attn_fwd_pf && g_attn_fwd_waves == 8) {
+    const size_t lds = 2 * 2 * 64 * 256;
+    const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;
+    if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+    (void)hipFuncSetAttribute((const void*)attn_fwd128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd128p_kernel, dim3((unsigned)nwg), dim3(512), lds, s, a);
+    return MM_OK;
+  }
   if (D == 128 && !attn_use_v1()) {
     const size_t lds = 2 * 2 * 64 * 256;
     const int qb = g_attn_fwd_waves * 32;
@@ -1555,7 +1904,10 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
     const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;     // 1-D grid: attn_work_item orders the blocks
     if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
     dim3 grid((unsigned)nwg), block(512);
-    if (g_attn_issue_waves == 4) {
+    if (g_attn_fwd_pf) {
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_bwd_dq128p_kernel, grid, block, lds, s, a);
+    } else if (g_attn_issue_waves == 4) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(attn_bwd_dq128_kernel<4>, grid, block, lds, s, a);
     } else {
@@ -1592,6 +1944,7 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
 
 int mm_attn_option(const char* name, int value) {   // reached through mm_set_option (mm_gemm.hip)
   if (!strcmp(name, "attn_dkv_pair")) { g_attn_dkv_pair = value != 0; return MM_OK; }
+  if (!strcmp(name, "attn_fwd_pf")) { g_attn_fwd_pf = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_fwd_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_attn_fwd_waves = value; return MM_OK; }
   return MM_ERR_ARG;
 }

@@ -43,6 +43,9 @@ struct GemmArgs {
   int swi_I;
   void* C2; int ldc2;
   const void* aux; int ldaux;   // MM_EPI_SWIGLU_BWD: the saved pre-activations [M, 2I]
+  // mm_gemm_sumsq: every wave adds up the squares of the (rounded) values it stores and writes ONE float to
+  // sumsq[workgroup * waves + wave] when the workgroup is done -- the global gradient norm without re-reading 16.7 GB
+  float* sumsq;
 };
 constexpr int MM_EPI_SWIGLU_BWD = 1 << 20;   // internal epilogue flag (mm_gemm_swiglu_bwd), not part of the ABI enum
 
@@ -156,7 +159,7 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
 
 // epilogue shared by the bf16 kernels: acc[i][j][r] = C[mw + i*16 + (l&15)][nw + j*16 + 4*(l>>4) + r]
 template <int MREP, int NREP>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, float& ss) {
   const int l = threadIdx.x & 63;
   bf16* C = (bf16*)g.C;
   const bf16* bias = (const bf16*)g.bias;
@@ -231,14 +234,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
       if (full) {
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+        for (int r = 0; r < 4; ++r) { o[r] = (bf16)v[r]; const float q = (float)o[r]; ss = __builtin_fmaf(q, q, ss); }
         *(bf16x4*)cp = o;      // default cache policy: non-temporal stores here measured -4 % (tools/build_diag.sh)
       } else {
         for (int r = 0; r < 4; ++r)
-          if (n + r < g.N) cp[r] = (bf16)v[r];
+          if (n + r < g.N) { const bf16 o = (bf16)v[r]; cp[r] = o; const float q = (float)o; ss = __builtin_fmaf(q, q, ss); }
       }
     }
   }
+}
+
+// one float per wave: the sum of squares of everything this wave stored (mm_gemm_sumsq); fixed slot, no atomics
+__device__ __forceinline__ void flush_sumsq(const GemmArgs& g, float ss, int nwaves) {
+  if (!g.sumsq) return;
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) g.sumsq[(int64_t)blockIdx.x * nwaves + (threadIdx.x >> 6)] = ss;
 }
 
 template <bool A_KC, bool B_KC>
@@ -294,7 +304,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue<4, 4>(g, acc, m0 + wm * 64, n0 + wn * 64);
+  float ss = 0.f;
+  gemm_epilogue<4, 4>(g, acc, m0 + wm * 64, n0 + wn * 64, ss);
+  flush_sumsq(g, ss, 4);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -567,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
     dma_tile<B_KC, BN_, ISSUE_WAVES>(st + A_BYTES, db, g.ldb, t * G_BK, g.K, swi);
   };
   static_assert(STAGES == 2, "the persistent stream below is written for the 2-stage ring");
+  float ss = 0.f;                                                     // sum of squares of this wave's stores (mm_gemm_sumsq)
   int sidx = 0;                                                       // global K-step counter (ring position)
   if (tile < total_full) issue(ra, rb, 0, 0);
   while (tile < total_full) {
@@ -635,7 +648,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
       }
     }
     if (swi) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
-    else gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    else gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN), ss);
     tile = next;
     m0 = nm0;
     n0 = nn0;
@@ -706,9 +719,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      gemm_epilogue<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
+      gemm_epilogue<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN), ss);
     }
   }
+  flush_sumsq(g, ss, 8);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -954,7 +968,9 @@ extern "C" int mm_get_option(const char* name, int* value) {
   return MM_ERR_ARG;
 }
 
-static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s);
+// slots: when non-null nothing is launched and *slots receives an upper bound of the sum-of-squares partials a launch of this
+// problem may write (16 per tile of the variant it would take); slot_cap: capacity of g.sumsq (checked before the launch)
+static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t* slots = nullptr, int64_t slot_cap = 0);
 
 extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                        int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream) {
@@ -995,7 +1011,33 @@ extern "C" int mm_gemm_swiglu_bwd(int dtype, int M, int I, int H, const void* dY
   return gemm_launch(g, dtype, MM_GEMM_NN, (hipStream_t)stream);
 }
 
-static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
+// C = A.B (any layout, MM_EPI_ACCUMULATE allowed) and, in the same pass, the sum of squares of the stored bf16 values:
+// the launch OVERWRITES partials[0 .. n) (n = its workgroups x waves <= capacity), one float per wave, and leaves the rest
+// alone: the caller zeroes the buffer once (per step) so that sum(partials[0 .. capacity)) = sum(C^2).  The weight-gradient GEMMs use
+// it so that clip_grad_norm_'s global norm (reference config_alignment.yaml:49, HF Trainer) costs no second pass over the
+// gradients.  mm_gemm_sumsq_slots gives the capacity to provide.  bf16 only; not for M <= 16 NT (decode) problems.
+extern "C" int mm_gemm_sumsq_slots(int dtype, int layout, int M, int N, int K, int64_t* slots) {
+  if (!slots || M <= 0 || N <= 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;
+  if (dtype != MM_BF16) return MM_ERR_UNSUPPORTED;
+  GemmArgs g{M, N, K, (const void*)16, (K + 7) / 8 * 8, (const void*)16, (K + 7) / 8 * 8, (void*)16, (N + 7) / 8 * 8};
+  if (layout == MM_GEMM_NN) g.ldb = (N + 7) / 8 * 8;
+  if (layout == MM_GEMM_TN) { g.lda = (M + 7) / 8 * 8; g.ldb = (N + 7) / 8 * 8; }
+  g.sumsq = (float*)16;
+  return gemm_launch(g, dtype, layout, nullptr, slots, 0);
+}
+
+extern "C" int mm_gemm_sumsq(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                             int ldc, int epilogue, float* partials, int64_t capacity, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;
+  if (dtype != MM_BF16) return MM_ERR_UNSUPPORTED;
+  if (!A || !B || !C || !partials || capacity <= 0 || (epilogue & ~MM_EPI_ACCUMULATE)) return MM_ERR_ARG;
+  if (M == 0 || N == 0) return hipMemsetAsync(partials, 0, (size_t)capacity * sizeof(float), (hipStream_t)stream) == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+  GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, epilogue};
+  g.sumsq = partials;
+  return gemm_launch(g, dtype, layout, (hipStream_t)stream, nullptr, capacity);
+}
+
+static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t* slots, int64_t slot_cap) {
   const int M = g.M, N = g.N, K = g.K, lda = g.lda, ldb = g.ldb, ldc = g.ldc, ldr = g.ldr, epilogue = g.epi;
   const void *A = g.A, *B = g.B;
   void* C = g.C;
@@ -1009,7 +1051,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'b' ? 3 : 2));
     }();
     const int forced = g_opt_kernel ? g_opt_kernel : forced_env;
-    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 && !g.swi_I &&
+    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 && !g.swi_I && !g.sumsq &&
         (int64_t)16 * lda * 2 < 0xFFFFFFFFll && (int64_t)16 * ldb * 2 < 0xFFFFFFFFll) {   // decode: stream W once
       dim3 grid((unsigned)((N + 15) / 16)), block(512);
       hipLaunchKernelGGL(gemm_skinny_kernel, grid, block, 0, s, g);
@@ -1034,6 +1076,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       g.nbn = g.swi_I ? g.swi_I / 128 : (N + bn - 1) / bn;
       const int64_t nwg = (int64_t)g.nbm * g.nbn;
       if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+      if (slots) { *slots = 16 * nwg; return MM_OK; }      // 8 waves x (tiles, or two half-tile workgroups per tile)
       const size_t lds = 2 * (bm + bn) * G_BK * 2;
       static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
       // persistent: one resident workgroup per CU walks the tiles; otherwise one tile each
@@ -1045,6 +1088,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
           nblk = nwg >= ncu ? ncu : 2 * rem;
         }
       }
+      if (g.sumsq && slot_cap < nblk * 8) return MM_ERR_ARG;       // slots beyond nblk*8 are left as they are (see mm_hip.h)
       dim3 grid((unsigned)nblk), block(512);
 #define MM_LAUNCH_ONE(...)                                                                                               \
   do {                                                                                                                   \
@@ -1073,6 +1117,8 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       g.nbn = (N + BN - 1) / BN;
       const int64_t nwg = (int64_t)g.nbm * g.nbn;
       if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+      if (slots) { *slots = 4 * nwg; return MM_OK; }
+      if (g.sumsq && slot_cap < nwg * 4) return MM_ERR_ARG;
       const size_t lds = 4 * TILE_BYTES;
       dim3 grid((unsigned)nwg), block(256);
       switch (layout) {
@@ -1082,6 +1128,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       }
     }
   } else if (dtype == MM_F32) {
+    if (g.sumsq || slots) return MM_ERR_UNSUPPORTED;
     g.nbm = (M + 63) / 64;
     g.nbn = (N + 63) / 64;
     dim3 grid((unsigned)(g.nbm * g.nbn)), block(256);

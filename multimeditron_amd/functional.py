@@ -83,7 +83,7 @@ def flush_deferred_wgrads():
                     dy.record_stream(side)
                     x.record_stream(side)
                     g, acc = wg.grad_target()
-                    K.linear_wgrad(dy, x, g, acc)
+                    K.linear_wgrad(dy, x, g, acc, sumsq=wg.sumsq_slots())
                     wg.ready()
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -143,6 +143,11 @@ class ParamGroup:
         for p in self.params:
             _ready(p)
 
+    def sumsq_slots(self):
+        """fp32 partial buffer the trainer attached to this group's first parameter (`_mm_ss`): the wgrad GEMM then also
+        produces the group's sum of squares for the global gradient norm.  None = not requested."""
+        return getattr(self.params[0], "_mm_ss", None)
+
 
 def as_group(p):
     return p if isinstance(p, ParamGroup) else ParamGroup([p])
@@ -188,7 +193,7 @@ class LinearFn(torch.autograd.Function):
                 _defer["items"].append((dy, x, wg))
             else:
                 g, acc = wg.grad_target()
-                K.linear_wgrad(dy, x, g, acc)
+                K.linear_wgrad(dy, x, g, acc, sumsq=wg.sumsq_slots())
                 wg.ready()
         dx = K.linear_dgrad(dy, wg.tensor()) if ctx.needs_input_grad[0] else None
         return dx, dres, None, None, None, None, None
@@ -444,7 +449,7 @@ class SwiGLUMLPFn(torch.autograd.Function):
                 _defer["items"].append((d_out, inp, group))
             else:
                 g, acc = group.grad_target()
-                K.linear_wgrad(d_out, inp, g, acc)
+                K.linear_wgrad(d_out, inp, g, acc, sumsq=group.sumsq_slots())
                 group.ready()
 
         wgrad(dy, act, wd)

@@ -40,9 +40,9 @@ def pad8(n: int) -> int:
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, out: Optional[torch.Tensor] = None,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = 0,
-         accumulate: bool = False, ldc_pad: bool = False) -> torch.Tensor:
+         accumulate: bool = False, ldc_pad: bool = False, sumsq: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw GEMM on 2-D row-major tensors (strides taken from .stride(0)).  Returns C [M, N] (a view of a padded
-    buffer when ldc_pad)."""
+    buffer when ldc_pad).  sumsq: fp32 partial buffer -> mm_gemm_sumsq (the GEMM also leaves sum(C^2) there)."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         if ldc_pad:
@@ -60,6 +60,11 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
         assert residual.stride(-1) == 1
     if accumulate:
         epi |= EPI_ACCUMULATE
+    if sumsq is not None:
+        assert bias is None and residual is None and act == 0
+        call("mm_gemm_sumsq", dt(a), layout, M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), epi, _p(sumsq),
+             sumsq.numel(), _stream())
+        return out
     call("mm_gemm", dt(a), layout, M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(bias),
          _p(residual), residual.stride(0) if residual is not None else 0, epi, _stream())
     return out
@@ -79,21 +84,33 @@ def linear_dgrad(dy2d, w, out=None):
     return gemm(GEMM_NN, dy2d, w, M, K, N, out=out)
 
 
-def linear_wgrad(dy2d, x2d, out, accumulate):
-    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]."""
+def linear_wgrad(dy2d, x2d, out, accumulate, sumsq=None):
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K].  sumsq: fp32 partial buffer -> the GEMM also leaves sum(dw^2) there (mm_gemm_sumsq)."""
     M, N = dy2d.shape
     K = x2d.shape[1]
-    return gemm(GEMM_TN, dy2d, x2d, N, K, M, out=out, accumulate=accumulate)
+    if dy2d.dtype != torch.bfloat16:
+        sumsq = None
+    return gemm(GEMM_TN, dy2d, x2d, N, K, M, out=out, accumulate=accumulate, sumsq=sumsq)
+
+
+def gemm_sumsq_slots(layout, M, N, K):
+    import ctypes
+    n = ctypes.c_int64(0)
+    call("mm_gemm_sumsq_slots", MM_BF16, layout, M, N, K, ctypes.byref(n))
+    return n.value
 
 
 import os as _os
-_FUSED_SWIGLU = _os.environ.get("MM_FUSED_SWIGLU", "1") != "0"      # A/B switch (bench only): 0 = GEMM + separate SwiGLU kernels
+
+
+def _fused_swiglu():      # A/B switch (tools/step_ab.py): MM_FUSED_SWIGLU=0 -> GEMM + separate SwiGLU kernels
+    return _os.environ.get("MM_FUSED_SWIGLU", "1") != "0"
 
 
 def gemm_swiglu_fwd(x2d, wgu, I):
     """(gu [M, 2I], act [M, I]) = fused gate|up GEMM + SwiGLU; None when the shape must take the two-launch form."""
     M, K = x2d.shape
-    if x2d.dtype != torch.bfloat16 or (I % 128) or (K % 64) or M < 256 or not _FUSED_SWIGLU:
+    if x2d.dtype != torch.bfloat16 or (I % 128) or (K % 64) or M < 256 or not _fused_swiglu():
         return None
     gu = torch.empty((M, 2 * I), dtype=x2d.dtype, device=x2d.device)
     act = torch.empty((M, I), dtype=x2d.dtype, device=x2d.device)
@@ -105,7 +122,7 @@ def gemm_swiglu_fwd(x2d, wgu, I):
 def gemm_swiglu_bwd(dy2d, wd, gu, I):
     """dgu [M, 2I] from dy [M, H], down_proj weight [H, I] and the saved pre-activations; None -> two-launch form."""
     M, H = dy2d.shape
-    if dy2d.dtype != torch.bfloat16 or (I % 4) or not _FUSED_SWIGLU:
+    if dy2d.dtype != torch.bfloat16 or (I % 4) or not _fused_swiglu():
         return None
     dgu = torch.empty_like(gu)
     call("mm_gemm_swiglu_bwd", dt(dy2d), M, I, H, _p(dy2d), dy2d.stride(0), _p(wd), wd.stride(0), _p(gu), gu.stride(0), _p(dgu),

@@ -104,50 +104,76 @@ class MultimodalTrainer:
         Fm.set_wgrad_deferral(self._wgrad_stream, ids)
 
     def _setup_early_gradnorm(self):
-        """The global gradient norm (clip_grad_norm_) reads every gradient once: 16.7 GB = 3.1 ms at the end of backward with
-        nothing beside it.  Most of those bytes are final long before: a decoder layer's seven weight gradients are complete
-        when its q/k/v wgrad has been enqueued.  So the sum of squares of each such layer (and of lm_head) is taken on a side
-        stream as soon as the layer is done, under the rest of backward; only what completes late (the deferred layers, the
-        embedding, the modality tower, vectors) is summed after backward.  Every chunk has its own partial slots and the
-        finish kernel adds the slots in a fixed order, so the norm does not depend on timing.  One GPU only: under data
-        parallelism a gradient is final only after its bucket's all-reduce.  MM_EARLY_NORM=0 disables."""
+        """Global gradient norm (clip_grad_norm_) without a second pass over the gradients.
+
+        A separate sum-of-squares sweep reads every gradient once: 16.7 GB = 3.1 ms at the end of backward with nothing
+        beside it.  Instead the weight-gradient GEMMs of the decoder (97 % of the parameters) and of an untied lm_head leave
+        the sum of squares of what they store in per-wave partial slots (`mm_gemm_sumsq`: fixed slots, no atomics, so the norm
+        is bit-reproducible); only the rest (embedding, modality tower, norm weights, biases) is swept by `sumsq_kernel`.
+        The finish kernel adds all partials in slot order.  One GPU only: under data parallelism a gradient is final only
+        after its bucket's all-reduce, so the sweep runs on the reduced buffer.  MM_FUSED_NORM=0 disables.
+
+        (Tried first and measured WORSE, kept behind MM_EARLY_NORM=1: sweeping each decoder layer on a side stream as soon as
+        its wgrads were enqueued, under the rest of backward: 409.2 vs 404.8 ms/step on one box -- the sweep's 16.7 GB of HBM
+        reads slow the GEMMs they run beside by more than the 3 ms they hide.)"""
         self._norm_chunks = [(s, e, None) for s, e, _ in self.ranges]       # (start, end, trigger param id or None)
         self._norm_triggers: Dict[int, int] = {}
         self._norm_stream = None
+        self._ss = None
+        for seg in self.flat.segments:                  # slots of an earlier trainer on this model are void
+            if hasattr(seg.param, "_mm_ss"):
+                del seg.param._mm_ss
         layers = getattr(getattr(self.model.model, "model", None), "layers", None)
-        if self.world > 1 or layers is None or not torch.cuda.is_available() or os.environ.get("MM_EARLY_NORM", "1") == "0":
+        fused = os.environ.get("MM_FUSED_NORM", "1") != "0" and self.flat.dtype == torch.bfloat16
+        early = os.environ.get("MM_EARLY_NORM", "0") == "1"
+        if self.world > 1 or layers is None or not torch.cuda.is_available() or not (fused or early):
             self._alloc_norm_partials()
             return
         seg_of = {id(sg.param): sg for sg in self._trainable}
-        early = []
+        covered = []                                     # (start, end, trigger id) of the ranges NOT swept at the end
+        groups = []                                      # (first param, [params]) whose wgrad GEMM produces its own sum of squares
         for layer in layers:
             a, m = layer.self_attn, layer.mlp
             mats = [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight, m.gate_proj.weight, m.up_proj.weight,
                     m.down_proj.weight]
-            if not all(id(p) in seg_of for p in mats) or Fm._is_deferred(a.q_proj.weight):
+            if not all(id(p) in seg_of for p in mats):
                 continue
             sgs = [seg_of[id(p)] for p in mats]
             if any((x.end + 7) // 8 * 8 != y.start for x, y in zip(sgs[:-1], sgs[1:])):
-                continue                                                   # not contiguous in the flat buffer: leave it late
-            early.append((sgs[0].start, (sgs[-1].end + 7) // 8 * 8, id(a.v_proj.weight)))     # q/k/v wgrad = the layer's last write
+                continue                                                   # not contiguous in the flat buffer: swept at the end
+            if fused:
+                groups += [mats[0:3], mats[3:4], mats[4:6], mats[6:7]]
+            elif Fm._is_deferred(a.q_proj.weight):
+                continue
+            covered.append((sgs[0].start, (sgs[-1].end + 7) // 8 * 8, id(a.v_proj.weight)))     # q/k/v wgrad = the layer's last write
         head = getattr(self.model.model, "lm_head", None)
         emb = self.model.model.get_input_embeddings().weight
         if head is not None and head.weight is not emb and id(head.weight) in seg_of:
             sg = seg_of[id(head.weight)]
-            early.append((sg.start, (sg.end + 7) // 8 * 8, id(head.weight)))
-        # late chunks = the trainable ranges minus the early ones
+            covered.append((sg.start, (sg.end + 7) // 8 * 8, id(head.weight)))
+            if fused:
+                groups.append([head.weight])
         late = []
         for s0, e0, _ in self.ranges:
             cur = s0
-            for a0, b0, _t in sorted(x for x in early if s0 <= x[0] and x[1] <= e0):
+            for a0, b0, _t in sorted(x for x in covered if s0 <= x[0] and x[1] <= e0):
                 if a0 > cur:
                     late.append((cur, a0, None))
                 cur = b0
             if cur < e0:
                 late.append((cur, e0, None))
-        if early:
-            self._norm_chunks = early + late
-            self._norm_triggers = {t: i for i, (_, _, t) in enumerate(early)}
+        if fused and groups:
+            from .._lib import GEMM_TN
+            sizes = [K.gemm_sumsq_slots(GEMM_TN, sum(p.shape[0] for p in g), g[0].shape[1], 4096) for g in groups]
+            self._ss = torch.zeros(sum(sizes), dtype=torch.float32, device=self.flat.device)
+            off = 0
+            for g, n in zip(groups, sizes):
+                g[0]._mm_ss = self._ss[off:off + n]        # functional.ParamGroup.sumsq_slots() hands it to the wgrad GEMM
+                off += n
+            self._norm_chunks = late
+        elif early and covered:
+            self._norm_chunks = covered + late
+            self._norm_triggers = {t: i for i, (_, _, t) in enumerate(covered)}
             self._norm_stream = torch.cuda.Stream()
         self._alloc_norm_partials()
 
@@ -158,7 +184,18 @@ class MultimodalTrainer:
             nb = int(min(1024, max(1, (e - s) // 65536)))
             self._norm_slots.append((off, nb))
             off += nb
-        self._norm_partial = torch.zeros(off, dtype=torch.float32, device=self.flat.device)
+        # one buffer for the finish kernel: [partials of the swept chunks | the wgrad GEMMs' slots]
+        n_ss = self._ss.numel() if self._ss is not None else 0
+        buf = torch.zeros(off + n_ss, dtype=torch.float32, device=self.flat.device)
+        if n_ss:
+            old = self._ss
+            self._ss = buf[off:]
+            for seg in self._trainable:                         # re-point the views handed out above into the joint buffer
+                v = getattr(seg.param, "_mm_ss", None)
+                if v is not None and v.untyped_storage().data_ptr() == old.untyped_storage().data_ptr():
+                    o0 = v.storage_offset() - old.storage_offset()
+                    seg.param._mm_ss = self._ss[o0:o0 + v.numel()]
+        self._norm_partial = buf
         self._norm_done = set()
         self._norm_armed = False
 
@@ -233,6 +270,8 @@ class MultimodalTrainer:
         last = self._micro == self.accum - 1
         if first:
             self.flat.attach_grads(fresh=True)       # no memset: the first wgrad of the step overwrites
+            if self._ss is not None:
+                self._ss.zero_()                     # the wgrad GEMMs overwrite their own slots; the rest must read 0
         ex = self.exchanger
         ex.begin_step(exchange_this_step=last)
         self._norm_done = set()
@@ -404,6 +443,21 @@ class MultimodalTrainer:
     def synchronize(self):
         """Make the compute stream wait for the in-flight optimiser update (call before reading parameters)."""
         self._wait_optimizer()
+
+    def close(self):
+        """Detach from the model (forward hooks, deferred-wgrad registration, gradient-norm slots) and release the optimiser
+        state, so that another trainer can be built on the same model (the hooks otherwise keep this one alive)."""
+        self._wait_optimizer()
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks = []
+        Fm.set_wgrad_deferral(None, ())
+        Fm.set_grad_ready_hook(None)
+        for seg in self.flat.segments:
+            if hasattr(seg.param, "_mm_ss"):
+                del seg.param._mm_ss
+        self.master = self.m = self.v = self._norm_partial = self._ss = None
+        self._blocks = []
 
     # ------------------------------------------------------------------ checkpoints (reference cli/train.py:186-195)
     def save_model(self, path: str, **kw):

@@ -93,32 +93,41 @@ def test_optimizer_overlap_hooks_cover_every_block(golden_dir, tmp_path, name):
     torch.cuda.synchronize()
 
 
-def test_early_gradnorm_chunks_equal_full_norm(golden_dir, tmp_path, monkeypatch):
-    """The global grad norm is assembled from per-layer sums of squares taken on a side stream DURING backward (layers whose
-    wgrads are final) plus the late remainder.  It must equal the norm of the complete flat gradient, and be identical
-    run to run (fixed partial slots, fixed summation order)."""
+@pytest.mark.parametrize("variant", ["fused", "early", "sweep"])
+def test_gradnorm_assembly_equals_full_norm(golden_dir, tmp_path, monkeypatch, variant):
+    """The global grad norm is assembled from the wgrad GEMMs' own sum-of-squares slots (mm_gemm_sumsq: decoder matrices,
+    lm_head) plus a sweep of the rest ("fused", the default), or from per-layer sweeps under backward ("early", an experiment
+    kept behind MM_EARLY_NORM=1), or from one sweep ("sweep").  Each must equal the norm of the complete flat gradient and be
+    identical run to run (fixed slots, fixed summation order); deferred and immediate wgrads both take part."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    monkeypatch.setenv("MM_DEFER_WGRAD_LAYERS", "1")          # layer 0 deferred (late chunk), layer 1 early
+    monkeypatch.setenv("MM_DEFER_WGRAD_LAYERS", "1")          # layer 0's wgrads deferred (side stream), layer 1's immediate
+    monkeypatch.setenv("MM_FUSED_NORM", "1" if variant == "fused" else "0")
+    monkeypatch.setenv("MM_EARLY_NORM", "1" if variant == "early" else "0")
     from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
     meta, w, v = R.load_golden("tiny_clip_llama", golden_dir)
     norms = []
     for rep in range(2):
         model = build_from_golden(meta, w, tmp_path / f"m{rep}", "bfloat16")
         tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=0.0, weight_decay=0.0, max_grad_norm=1.0)
-        assert tr._norm_triggers, "no early chunk was set up"
-        assert len(tr._norm_chunks) > len(tr._norm_triggers)
-        covered = sorted((s, e) for s, e, _ in tr._norm_chunks)
-        assert sum(e - s for s, e in covered) == sum(e - s for s, e, _ in tr.ranges)
-        assert all(a[1] <= b[0] for a, b in zip(covered[:-1], covered[1:])), "chunks overlap"
-        tr.training_step(to_device(R.golden_batch(v, "right")))
-        assert set(tr._norm_triggers.values()) <= tr._norm_done
+        if variant == "fused":
+            assert tr._ss is not None and tr._ss.numel() > 0 and not tr._norm_triggers
+            fused_elems = sum(e - s for s, e, _ in tr.ranges) - sum(e - s for s, e, _ in tr._norm_chunks)
+            assert fused_elems > 0.5 * sum(p.numel() for p in model.model.model.layers.parameters())
+        elif variant == "early":
+            assert tr._norm_triggers and tr._ss is None
+        else:
+            assert tr._ss is None and not tr._norm_triggers and len(tr._norm_chunks) == len(tr.ranges)
+        spans = sorted((s, e) for s, e, _ in tr._norm_chunks)
+        assert all(a[1] <= b[0] for a, b in zip(spans[:-1], spans[1:])), "chunks overlap"
+        for _ in range(2):                                     # twice: slots are reused step after step
+            tr.training_step(to_device(R.golden_batch(v, "right")))
         tr.synchronize()
         torch.cuda.synchronize()
         g = tr.flat.grad
         ref = torch.sqrt(sum((g[s:e].double() ** 2).sum() for s, e, _ in tr.ranges))
         got = tr.last_grad_norm[0].double()
-        assert abs(float(got) - float(ref)) < 1e-5 * float(ref), (float(got), float(ref))
+        assert abs(float(got) - float(ref)) < 1e-5 * float(ref), (variant, float(got), float(ref))
         norms.append(tr.last_grad_norm.clone())
     assert torch.equal(norms[0], norms[1])
 

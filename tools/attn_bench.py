@@ -51,6 +51,15 @@ if "--ab-fwdwaves" in sys.argv:  # forward: one 8-wave workgroup per CU vs two i
     lib().mm_set_option(b"attn_fwd_waves", 8)
     run(2, 4096, 32, 8, 128, True)
     sys.exit(0)
+if "--ab-pf" in sys.argv:        # D=128 forward: serialized fragment reads vs the prefetching kernel (same process, interleaved)
+    for v in (0, 1, 0, 1):
+        lib().mm_set_option(b"attn_fwd_pf", v)
+        print("attn_fwd_pf", v)
+        run(4, 2048, 32, 8, 128, True)
+    run(2, 4096, 32, 8, 128, True)
+    run(4, 2048, 28, 4, 128, True)
+    run(4, 2048, 32, 8, 128, True, mask=True)
+    sys.exit(0)
 if "--quick" in sys.argv:
     run(4, 2048, 32, 8, 128, True)
     run(4, 2048, 32, 8, 128, True)
