@@ -1448,6 +1448,230 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pair_kernel(AttnArgs a
   }
 }
 
+// dK/dV for D = 128, paired key blocks, with prefetched fragments.  attn_bwd_dkv128_pair_kernel's ISA had the same disease as
+// the forward (every MFMA behind its own ds_read + lgkmcnt(0), one register quad for all fragments) and a worse one: the 32 row
+// constants (lse, delta) of a query tile were fetched by 17 ds_read2_b32, each followed by lgkmcnt(0) -- 17 dependent LDS
+// round trips per 32-MFMA iteration; rocprofv3: waves parked 69 % of their cycles.  Here (same arithmetic and rounding, results
+// bit-identical):
+//   * all tiles (V and K images of the 128 keys, the teams' Q / dO rings) are image (a): base + constant addressing;
+//   * K is an LDS image like V instead of 32 registers of fragments: that pays for a 4-deep fragment ring over the 48
+//     fragments of an iteration (Q, K, dO, V row fragments for S^T and dP^T; dO^T, Q^T transposed fragments for dV, dK);
+//   * the row constants are read as eight 16-byte vectors (rows 8g + 4h .. + 3 are consecutive), issued together.
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs a) {
+  constexpr int BQ = 32, NDB = 4, QT = BQ * 256, IMG = 128 * 256;     // 8 KiB per 32-row tile, 32 KiB per 128-key image
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [V image | K image | 2 teams x 2 stages x (Q | dO) | row constants]
+  const int l = threadIdx.x & 63, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: LDS-DMA addresses live in SGPRs
+  const int team = w >> 2, wt = w & 3, tt = threadIdx.x & 255;
+  float* red = (float*)(smem + 2 * IMG);                               // 64 KiB = both rings, reused for the team sum
+  float* rowc = (float*)(smem + 2 * IMG + 8 * QT) + team * 128;        // per team [2 stages][lse*log2e (32) | delta (32)]
+  const int b = blockIdx.z, hkv = blockIdx.y;
+  const int G = a.Hq / a.Hkv, GH = G / 2;
+  const int nkb = (a.Skv + 127) / 128;
+  const int shift = a.Skv - a.Sq;
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const unsigned ring0 = lds0 + 2 * IMG + (unsigned)(team * 4 * QT);
+  const float sc = a.scale * LOG2E;
+  const int nqt = (a.Sq + BQ - 1) / BQ;
+  const int64_t do_ss = (int64_t)a.Hq * 128;
+  const ImgaBases bases = imga_bases(smem, 0);
+  // per-lane bases: key images at this wave's 32 keys (row fragments), this team's ring (row + transposed fragments)
+  const char* vrow[2] = {bases.kr[0] + 2048 * 4 * wt, bases.kr[1] + 2048 * 4 * wt};
+  const char* ring_r[2] = {bases.kr[0] + 2 * IMG + team * 4 * QT, bases.kr[1] + 2 * IMG + team * 4 * QT};
+  const char* ring_t[2] = {bases.vt[0] + 2 * IMG + team * 4 * QT, bases.vt[1] + 2 * IMG + team * 4 * QT};
+  // DMA source patterns (image (a)): a 1-KiB piece = 8 rows x 128 B, lane pattern s = (piece >> 1) & 1
+  unsigned lk[2], lv[2], lq, ldo;
+  imga_lane_patterns(lk, lv, a.k_ss, a.v_ss);
+  {
+    const int rl = (l >> 2) & 7, cl = 4 * (l >> 5) + ((l & 3) ^ (((wt & 1) << 1) | ((l >> 4) & 1)));   // this wave's ring pieces: 2wt, 2wt+1
+    lq = (unsigned)((int64_t)rl * a.q_ss * 2 + cl * 16);
+    ldo = (unsigned)((int64_t)rl * do_ss * 2 + cl * 16);
+  }
+
+  for (int pass = 0; pass < 2; ++pass) {
+    const int kb = pass == 0 ? (int)blockIdx.x : nkb - 1 - (int)blockIdx.x;
+    if (pass == 1 && kb <= (int)blockIdx.x) break;                    // odd count: the middle block has no partner
+    const int kblk = kb * 128;
+    const int k0 = kblk + wt * 32;
+    const int ki = k0 + (l & 31);
+    {   // V and K images of the 128 keys: 32 pieces each, 4 per wave
+      const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+      const SRsrc rk = rows_rsrc((const bf16*)a.k + b * a.k_sb + hkv * a.k_sh, a.Skv, a.k_ss);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pc = w * 4 + i, prow = kblk + 8 * (pc >> 1);
+        lds_dma16(rv, lv[i >> 1] + (unsigned)((int64_t)prow * a.v_ss * 2 + (i & 1) * 128), lds0 + pc * 1024);
+        lds_dma16(rk, lk[i >> 1] + (unsigned)((int64_t)prow * a.k_ss * 2 + (i & 1) * 128), lds0 + IMG + pc * 1024);
+      }
+    }
+    bool kvalid = ki < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + ki] != 0;
+    f32x16 dk_acc[NDB], dv_acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk_acc[i][r] = 0.f; dv_acc[i][r] = 0.f; }
+
+    int qt0 = 0;
+    if (a.causal) qt0 = max(0, kblk - shift) / BQ;
+    const int per_head = max(0, nqt - qt0);
+    const int niter = per_head * GH;                                   // the same count for both teams
+    float rc = 0.f;
+    auto issue = [&](int it) {
+      const int g = team * GH + it / per_head, qb = (qt0 + it % per_head) * BQ;
+      const int hq = hkv * G + g;
+      const SRsrc rq = rows_rsrc((const bf16*)a.q + b * a.q_sb + hq * a.q_sh, a.Sq, a.q_ss);
+      const SRsrc rdo = rows_rsrc((const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128, a.Sq, do_ss);
+      const unsigned st = ring0 + (unsigned)((it & 1) * 2 * QT) + (unsigned)(wt * 2) * 1024u;
+      const int prow = qb + 8 * wt;                                    // this wave's two pieces of each tile: rows 8wt .. 8wt+7
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        lds_dma16(rq, lq + (unsigned)((int64_t)prow * a.q_ss * 2 + i * 128), st + i * 1024);
+        lds_dma16(rdo, ldo + (unsigned)((int64_t)prow * do_ss * 2 + i * 128), st + QT + i * 1024);
+      }
+      if (tt < 64) {
+        const int qq = qb + (tt & 31);
+        const int64_t ro = ((int64_t)b * a.Hq + hq) * a.Sq + qq;
+        if (tt < 32) rc = qq < a.Sq ? a.lse[ro] * LOG2E : INFINITY;
+        else rc = qq < a.Sq ? a.delta[ro] : 0.f;
+      }
+    };
+    if (niter > 0) {
+      issue(0);
+      if (tt < 64) rowc[tt] = rc;
+    }
+    for (int it = 0; it < niter; ++it) {
+      const int qb = (qt0 + it % per_head) * BQ;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (it + 1 < niter) issue(it + 1);
+      const int so = (it & 1) * 2 * QT;
+      const float* rcs = rowc + (it & 1) * 64;
+      if (!(a.causal && k0 > qb + BQ - 1 + shift)) {
+        // fragment j of the 48: j < 32: k-step j >> 2, kind j & 3 (0: Q rows, 1: K rows, 2: dO rows, 3: V rows);
+        //                       j >= 32: d block (j - 32) >> 2, 16-query step ((j - 32) >> 1) & 1, kind (j & 1) (0: dO^T, 1: Q^T)
+        auto frag = [&](int j) -> bf16x8 {
+          if (j < 32) {
+            const int ds = j >> 2, kind = j & 3, a2 = ds & 1, off = 512 * (ds >> 1);
+            if (kind == 0) return *(const bf16x8*)(ring_r[a2] + so + off);
+            if (kind == 1) return *(const bf16x8*)(vrow[a2] + IMG + off);
+            if (kind == 2) return *(const bf16x8*)(ring_r[a2] + so + QT + off);
+            return *(const bf16x8*)(vrow[a2] + off);
+          }
+          const int jj = j - 32, db = jj >> 2, s16 = (jj >> 1) & 1, kind = jj & 1;
+          const int off = so + (kind == 0 ? QT : 0) + 4096 * s16 + 512 * db;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, ring_t[0] + off));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, ring_t[1] + off));
+          bf16x8 o;
+          o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+          o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+          return o;
+        };
+        constexpr int RD = 4;
+        // row constants of the lane's 16 query rows: rows 8g + 4h + (0..3), g = 0..3 -> 4 + 4 vectors of 16 bytes
+        f32x4 lsev[4], dltv[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          lsev[g4] = *(const f32x4*)(rcs + 8 * g4 + 4 * h);
+          dltv[g4] = *(const f32x4*)(rcs + 32 + 8 * g4 + 4 * h);
+        }
+        f32x16 s_acc, dp_acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
+        bf16x8 fr[RD];                                                 // ring: fragment j lives in fr[j % RD]
+#pragma unroll
+        for (int j = 0; j < RD; ++j) fr[j] = frag(j);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {                                 // MFMA m uses fragments 2m (A) and 2m + 1 (B); once it is
+          if (m & 1) dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], dp_acc, 0, 0, 0);   // issued
+          else s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], s_acc, 0, 0, 0);          // their slots
+          fr[(2 * m) % RD] = frag(2 * m + RD);                         // take the fragments of MFMA m + 2 (the last two chunks
+          fr[(2 * m + 1) % RD] = frag(2 * m + 1 + RD);                 // already fetch transposed fragments 32 .. 35)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        bf16x8 pf[2], dsf[2];
+        const bool need_mask = (__ballot(kvalid) != ~0ull) || (a.causal && (k0 + 31) > (qb + shift));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = acc_row(r, h);
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], sc, -lsev[r >> 2][r & 3]));
+          if (need_mask) {
+            bool ok = kvalid;
+            if (a.causal) ok = ok && ki <= (qb + ql + shift);
+            p = ok ? p : 0.f;
+          }
+          const float dsv = p * (dp_acc[r] - dltv[r >> 2][r & 3]) * a.scale;
+          pf[r >> 3][r & 7] = (bf16)p;
+          dsf[r >> 3][r & 7] = (bf16)dsv;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {                                 // fragment 32 + m: d block m >> 2, query step (m >> 1) & 1
+          const int db = m >> 2, s16 = (m >> 1) & 1;
+          if (m & 1) dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(32 + m) % RD], dsf[s16], dk_acc[db], 0, 0, 0);
+          else dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(32 + m) % RD], pf[s16], dv_acc[db], 0, 0, 0);
+          if (32 + m + RD < 48) fr[(32 + m) % RD] = frag(32 + m + RD);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      if (it + 1 < niter && tt < 64) rowc[((it + 1) & 1) * 64 + tt] = rc;
+    }
+    // ---- sum the two teams' accumulators through LDS (team 1 writes, team 0 adds: fixed order), then team 0 stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                   // every wave has left the rings and the V image
+    float* mine = red + (wt * 64) * 64 + l;                            // [wave-in-team][64 values][lane]
+    if (team == 1) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(db * 16 + r) * 64] = dk_acc[db][r];
+    }
+    __syncthreads();
+    if (team == 0) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk_acc[db][r] += mine[(db * 16 + r) * 64];
+    }
+    __syncthreads();
+    if (team == 1) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(db * 16 + r) * 64] = dv_acc[db][r];
+    }
+    __syncthreads();
+    if (team == 0) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dv_acc[db][r] += mine[(db * 16 + r) * 64];
+      if (ki < a.Skv) {
+        bf16* dkrow = (bf16*)a.dk + b * a.k_sb + hkv * a.k_sh + (int64_t)ki * a.k_ss;
+        bf16* dvrow = (bf16*)a.dv + b * a.v_sb + hkv * a.v_sh + (int64_t)ki * a.v_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            bf16x4 ok_, ov_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ok_[e] = (bf16)dk_acc[db][rg * 4 + e];
+              ov_[e] = (bf16)dv_acc[db][rg * 4 + e];
+            }
+            *(bf16x4*)(dkrow + db * 32 + 8 * rg + 4 * h) = ok_;
+            *(bf16x4*)(dvrow + db * 32 + 8 * rg + 4 * h) = ov_;
+          }
+      }
+    }
+    __syncthreads();                                                   // `red` is free again before the next pass's DMA
+  }
+}
+
 // dQ for D = 128 with prefetched fragments (same treatment as attn_fwd128p_kernel: image (a), base + constant addressing, a
 // 4-deep fragment ring; same arithmetic and rounding as attn_bwd_dq128_kernel, bit-identical results).  Per 32-key step the
 // wave reads 16 row fragments (K for S^T = K.Q^T, V for dP^T = V.dO^T) and 8 transposed K fragments (dQ^T += K^T.dS^T) -- all
@@ -1921,11 +2145,17 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
   }
   if (D == 128 && !attn_use_v1()) {
     if (((a.Hq / a.Hkv) & 1) == 0 && g_attn_dkv_pair) {
-      const size_t lds = 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);
       const int nkb = (a.Skv + 127) / 128;
       dim3 grid((nkb + 1) / 2, a.Hkv, a.B), block(512);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_bwd_dkv128_pair_kernel, grid, block, lds, s, a);
+      if (g_attn_fwd_pf) {
+        const size_t lds = 2 * 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);      // V + K images, rings, row constants
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pairp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(attn_bwd_dkv128_pairp_kernel, grid, block, lds, s, a);
+      } else {
+        const size_t lds = 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(attn_bwd_dkv128_pair_kernel, grid, block, lds, s, a);
+      }
     } else {
       const size_t lds = 128 * 256 + 4 * 32 * 256 + 2 * 64 * sizeof(float);
       dim3 grid((a.Skv + 127) / 128, a.Hkv, a.B), block(256);
