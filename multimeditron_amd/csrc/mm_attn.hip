@@ -1008,7 +1008,7 @@ __device__ __forceinline__ void imga_issue_kv(int w, unsigned st, int row0, cons
 
 __global__ __launch_bounds__(512, 2) void attn_fwd128p_kernel(AttnArgs a) {
   constexpr int QB = 256, BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][K 16 KiB | V 16 KiB]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][K 16 KiB | V 16 KiB]
   const int l = threadIdx.x & 63, h = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int qblk, b, hq;
@@ -1047,18 +1047,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128p_kernel(AttnArgs a) {
   // i.e. one of TWO lane patterns (pieces 4w, 4w+1 -> s = 0; 4w+2, 4w+3 -> s = 1) plus a wave-uniform offset.
   unsigned lk[2], lv[2];
   imga_lane_patterns(lk, lv, a.k_ss, a.v_ss);
+  // 3-stage ring: the tiles of step t+2 are requested while t is computed.  With 2 stages (request t+1 after the barrier of t,
+  // vmcnt(0) at the next barrier) a tile had ONE 32-MFMA step (~0.9 us) to arrive, about the loaded-chip LDS-DMA latency:
+  // rocprofv3 still showed the waves parked 35 % of their cycles after the fragment prefetch went in.  An issuing wave has 8
+  // DMA pieces per tile in flight, so `vmcnt(8)` retires tile t and leaves t+1 under way.
+  constexpr int NST = 3;
   auto issue = [&](int t) {
-    imga_issue_kv(w, lds0 + (unsigned)((t & 1) * 2 * TILE), t * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
+    imga_issue_kv(w, lds0 + (unsigned)((t % NST) * 2 * TILE), t * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
   };
   if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * BKV;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 1 < ntiles) issue(t + 1);
+    if (t + 2 < ntiles) issue(t + 2);
     // wave-uniform skip: this wave's rows are all beyond Sq, or the whole tile lies above its causal diagonal
     if (q0 >= a.Sq || (a.causal && kv0 > q0 + 31 + shift)) continue;
-    const int so = (t & 1) * 2 * TILE;
+    const int so = (t % NST) * 2 * TILE;
     bool kvalid = (kv0 + l) < a.Skv;
     if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + kv0 + l] != 0;
     const unsigned long long kbits = __ballot(kvalid);
@@ -1086,13 +1093,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128p_kernel(AttnArgs a) {
 #pragma unroll
     for (int j = 0; j < RD - 1; ++j) vf[j] = imga_vfrag(bases, so, j >> 2, j & 3);
     if (need_mask) {
+      // key kl = c + 4h with c a compile-time constant per accumulator register: shift the key bits and the causal limit by
+      // the lane's 4h ONCE, so every test is against an immediate (32 hoisted per-register key indices cost 14 spilled VGPRs)
+      const unsigned long long kb2 = kbits >> (4 * h);
+      const int dlim = a.causal ? (qi + shift - kv0 - 4 * h) : 0x7fffffff;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kl = kb * 32 + acc_row(r, h);
-          bool ok = (kbits >> kl) & 1ull;
-          if (a.causal) ok = ok && (kv0 + kl) <= (qi + shift);
+          const int c = kb * 32 + (r & 3) + 8 * (r >> 2);
+          const bool ok = ((kb2 >> c) & 1ull) && c <= dlim;
           s_acc[kb][r] = ok ? s_acc[kb][r] : -INFINITY;
         }
     }
@@ -1723,14 +1733,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq128p_kernel(AttnArgs a) {
   }
   unsigned lk[2], lv[2];
   imga_lane_patterns(lk, lv, a.k_ss, a.v_ss);
+  constexpr int NST = 3;                                         // 3-stage ring, counted vmcnt: see attn_fwd128p_kernel
   if (ntiles > 0) imga_issue_kv(w, lds0, 0, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
+  if (ntiles > 1) imga_issue_kv(w, lds0 + 2 * TILE, BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * BKV;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 1 < ntiles) imga_issue_kv(w, lds0 + (unsigned)(((t + 1) & 1) * 2 * TILE), (t + 1) * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
+    if (t + 2 < ntiles) imga_issue_kv(w, lds0 + (unsigned)(((t + 2) % NST) * 2 * TILE), (t + 2) * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
     if (q0 >= a.Sq || (a.causal && kv0 > q0 + 31 + shift)) continue;
-    const int so = (t & 1) * 2 * TILE;
+    const int so = (t % NST) * 2 * TILE;
     bool kvalid = (kv0 + l) < a.Skv;
     if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + kv0 + l] != 0;
     const unsigned long long kbits = __ballot(kvalid);
@@ -2091,7 +2104,7 @@ static bool attn_use_v1() {
 template <int D>
 int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
   if (D == 128 && !attn_use_v1() && g_attn_fwd_pf && g_attn_fwd_waves == 8) {
-    const size_t lds = 2 * 2 * 64 * 256;
+    const size_t lds = 3 * 2 * 64 * 256;
     const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;
     if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
     (void)hipFuncSetAttribute((const void*)attn_fwd128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2129,8 +2142,9 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
     if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
     dim3 grid((unsigned)nwg), block(512);
     if (g_attn_fwd_pf) {
-      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_bwd_dq128p_kernel, grid, block, lds, s, a);
+      const size_t lds3 = 3 * 2 * 64 * 256;
+      (void)hipFuncSetAttribute((const void*)attn_bwd_dq128p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      hipLaunchKernelGGL(attn_bwd_dq128p_kernel, grid, block, lds3, s, a);
     } else if (g_attn_issue_waves == 4) {
       (void)hipFuncSetAttribute((const void*)attn_bwd_dq128_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(attn_bwd_dq128_kernel<4>, grid, block, lds, s, a);

@@ -104,18 +104,18 @@ class MultimodalTrainer:
         Fm.set_wgrad_deferral(self._wgrad_stream, ids)
 
     def _setup_early_gradnorm(self):
-        """Global gradient norm (clip_grad_norm_) without a second pass over the gradients.
+        """Global gradient norm (clip_grad_norm_): how the sum of squares of 16.7 GB of gradients is taken.
 
-        A separate sum-of-squares sweep reads every gradient once: 16.7 GB = 3.1 ms at the end of backward with nothing
-        beside it.  Instead the weight-gradient GEMMs of the decoder (97 % of the parameters) and of an untied lm_head leave
-        the sum of squares of what they store in per-wave partial slots (`mm_gemm_sumsq`: fixed slots, no atomics, so the norm
-        is bit-reproducible); only the rest (embedding, modality tower, norm weights, biases) is swept by `sumsq_kernel`.
-        The finish kernel adds all partials in slot order.  One GPU only: under data parallelism a gradient is final only
-        after its bucket's all-reduce, so the sweep runs on the reduced buffer.  MM_FUSED_NORM=0 disables.
-
-        (Tried first and measured WORSE, kept behind MM_EARLY_NORM=1: sweeping each decoder layer on a side stream as soon as
-        its wgrads were enqueued, under the rest of backward: 409.2 vs 404.8 ms/step on one box -- the sweep's 16.7 GB of HBM
-        reads slow the GEMMs they run beside by more than the 3 ms they hide.)"""
+        DEFAULT: one sweep (`sumsq_kernel`, 5.4 TB/s = 3.1 ms) over the trainable ranges after backward, partials summed in a
+        fixed order by the finish kernel.  Two ways to hide those 3 ms were built, measured on the 8B step with
+        tools/step_ab.py (same box, same process, interleaved) and found to COST time; they stay behind switches:
+          * MM_FUSED_NORM=1 -- the decoder's weight-gradient GEMMs (97 % of the parameters) and an untied lm_head leave the
+            sum of squares of what they store in per-wave slots (`mm_gemm_sumsq`: no atomics, bit-reproducible) and only the
+            rest is swept: 399.6 vs 395.5 ms/step.  The epilogue's extra convert + FMA per stored element (512 VALU
+            instructions per lane and 256x256 tile) lengthens every wgrad GEMM by more than the sweep it replaces.
+          * MM_EARLY_NORM=1 -- each decoder layer swept on a side stream as soon as its wgrads are enqueued, under the rest
+            of backward: 409.2 vs 404.8 ms/step: the sweep's HBM reads slow the GEMMs they run beside.
+        One GPU only in both cases: under data parallelism a gradient is final only after its bucket's all-reduce."""
         self._norm_chunks = [(s, e, None) for s, e, _ in self.ranges]       # (start, end, trigger param id or None)
         self._norm_triggers: Dict[int, int] = {}
         self._norm_stream = None
@@ -124,7 +124,7 @@ class MultimodalTrainer:
             if hasattr(seg.param, "_mm_ss"):
                 del seg.param._mm_ss
         layers = getattr(getattr(self.model.model, "model", None), "layers", None)
-        fused = os.environ.get("MM_FUSED_NORM", "1") != "0" and self.flat.dtype == torch.bfloat16
+        fused = os.environ.get("MM_FUSED_NORM", "0") == "1" and self.flat.dtype == torch.bfloat16
         early = os.environ.get("MM_EARLY_NORM", "0") == "1"
         if self.world > 1 or layers is None or not torch.cuda.is_available() or not (fused or early):
             self._alloc_norm_partials()

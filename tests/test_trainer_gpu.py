@@ -96,8 +96,8 @@ def test_optimizer_overlap_hooks_cover_every_block(golden_dir, tmp_path, name):
 @pytest.mark.parametrize("variant", ["fused", "early", "sweep"])
 def test_gradnorm_assembly_equals_full_norm(golden_dir, tmp_path, monkeypatch, variant):
     """The global grad norm is assembled from the wgrad GEMMs' own sum-of-squares slots (mm_gemm_sumsq: decoder matrices,
-    lm_head) plus a sweep of the rest ("fused", the default), or from per-layer sweeps under backward ("early", an experiment
-    kept behind MM_EARLY_NORM=1), or from one sweep ("sweep").  Each must equal the norm of the complete flat gradient and be
+    lm_head) plus a sweep of the rest ("fused", MM_FUSED_NORM=1), or from per-layer sweeps under backward ("early", an experiment
+    kept behind MM_EARLY_NORM=1), or from one sweep ("sweep", the default since both alternatives measured slower).  Each must equal the norm of the complete flat gradient and be
     identical run to run (fixed slots, fixed summation order); deferred and immediate wgrads both take part."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")

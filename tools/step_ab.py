@@ -42,9 +42,14 @@ def endless():
 res = {v: [] for v in args.variants}
 for r in range(args.rounds):
     for v in args.variants:
-        saved = {}
+        saved, opts = {}, []
         for kv in v.split(","):
             k, val = kv.split("=")
+            if k.startswith("opt:"):            # a libmmhip switch (mm_set_option), e.g. opt:attn_fwd_pf=0
+                from multimeditron_amd._lib import lib
+                assert lib().mm_set_option(k[4:].encode(), int(val)) == 0, k
+                opts.append(k[4:])
+                continue
             saved[k] = os.environ.get(k)
             os.environ[k] = val
         tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=1e-4, weight_decay=0.01, max_grad_norm=1.0,
@@ -65,6 +70,8 @@ for r in range(args.rounds):
         del tr, feed
         import gc
         gc.collect()
+        for k in opts:                          # switches default to 1 in this tool's use
+            lib().mm_set_option(k.encode(), 1)
         for k, val in saved.items():
             if val is None:
                 os.environ.pop(k, None)
