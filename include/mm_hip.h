@@ -233,6 +233,23 @@ int mm_gradnorm_finish(const float* partial, int nblk, float max_norm, float* to
 int mm_adamw_step(int dtype, void* p, const void* g, float* master, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* clip, void* stream);
 
+/* ---- gradient exchange over RCCL (one communicator per process = per GPU) -------------------------------------------
+ * Replaces the reference's DeepSpeed gradient reduce / parameter gather (config/deepspeed.json:5-19) and the NCCL process
+ * group torch.distributed builds for it (cli/train.py:200-201).  RCCL is bound at run time (dlopen); without it every call
+ * returns MM_ERR_UNSUPPORTED.  mm_comm_unique_id: rank 0 makes the 128-byte id, the caller carries it to the other ranks
+ * (any side channel: the torchrun store, a file, MPI) and every rank calls mm_comm_init on ITS device (hipSetDevice first).
+ * All collectives are in place, sum, enqueued on `stream` (asynchronous; the caller orders them with events).
+ * mm_comm_allreduce_bucket algo: 0 = ncclAllReduce, 1 = reduce-scatter + all-gather in one group (shard r = rank r's; the
+ * tail count % world through a small all-reduce).  mm_comm_reduce_scatter / mm_comm_all_gather: the halves on their own for
+ * a sharded optimiser step (count % world == 0; shard = count / world elements at buf + rank * shard).                     */
+int mm_comm_unique_id(void* id128);
+int mm_comm_init(const void* id128, int rank, int world, void** comm_out);
+int mm_comm_rank(void* comm, int* rank, int* world);
+int mm_comm_allreduce_bucket(void* comm, int dtype, void* buf, int64_t count, int algo, void* stream);
+int mm_comm_reduce_scatter(void* comm, int dtype, void* buf, int64_t count, void* stream);
+int mm_comm_all_gather(void* comm, int dtype, void* buf, int64_t count, void* stream);
+int mm_comm_finalize(void* comm);
+
 /* ---- utilities ---------------------------------------------------------------------------------------------------- */
 int mm_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
 int mm_fill_zero(void* p, int64_t bytes, void* stream);

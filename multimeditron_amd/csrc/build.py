@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmmhip.so")
-SOURCES = ["mm_gemm.hip", "mm_attn.hip", "mm_rowwise.hip", "mm_embed.hip", "mm_optim.hip", "mm_debug.hip"]
+SOURCES = ["mm_gemm.hip", "mm_attn.hip", "mm_rowwise.hip", "mm_embed.hip", "mm_optim.hip", "mm_debug.hip", "mm_comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 
@@ -46,7 +46,7 @@ def build(force=False, verbose=True):
         list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(OUT, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

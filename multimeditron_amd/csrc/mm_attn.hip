@@ -34,6 +34,8 @@ struct AttnArgs {
   const void* dout;
   const float* delta;
   void *dq, *dk, *dv;
+  int diag;   // timing experiments on attn_fwd128q_kernel (results wrong by design): 1 no DMA, 2 no softmax VALU, 4 no QK^T MFMAs, 8 no PV MFMAs, 16 no LDS fragment reads
+  int prio;   // s_setprio policy of the out-of-phase kernels: 0 none, 1 around every MFMA segment, 2 static for waves 4-7, 3 static for waves 0-3
 };
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -1154,6 +1156,224 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128p_kernel(AttnArgs a) {
   }
 }
 
+// ---- D = 128 forward, 8 waves, the two waves of a SIMD OUT OF PHASE ---------------------------------------------------------
+// attn_fwd128p_kernel keeps the matrix pipe 33 % busy: its eight waves leave every barrier together, so the two waves of a SIMD
+// are in the same segment at the same time -- QK^T beside QK^T (matrix pipe shared), softmax beside softmax (VALU shared,
+// matrix pipe idle), PV beside PV.  Per key tile and wave the softmax is ~1470 VALU cycles against 2 x 512 MFMA cycles, so the
+// SIMD's two waves need 2940 VALU + 2048 MFMA cycles and spend them one after the other (MI355X_MICROARCH.md, "Two waves per
+// SIMD", items 1 and 5: what a barrier interval PAIRS is the lever).
+// Here the halves run the same three segments per tile but the barrier sits at a different place in each:
+//     late half  (waves 0-3, the DMA issuers):   b_k | S(k)        softmax(k)   PV(k)
+//     early half (waves 4-7):                    b_k | softmax(k)  PV(k)        S(k+1)
+// so one wave's MFMA segments face its partner's softmax.  The early half reads K(k+1) one interval ahead and both read V(k)
+// in interval k, hence a 4-slot K/V ring: tile k+3 is requested at b_k into the slot of tile k-1 (last read before b_k by
+// both halves); tile k+1 has landed before b_k (`vmcnt(8)`: only tile k+2 may still be in flight).  Same arithmetic, same
+// rounding points, same per-row results as attn_fwd128p_kernel (bit-identical).
+#ifdef MM_ATTN_QDIAG               // timing experiments (results wrong by design), tools/build_diag.sh: AttnArgs::diag bits
+#define MM_QDIAG a.diag
+#else
+#define MM_QDIAG 0
+#endif
+template <int RD>                      // fragment ring depth: RD - 1 LDS reads in flight ahead of every MFMA
+__global__ __launch_bounds__(512, 2) void attn_fwd128q_kernel(AttnArgs a) {
+  constexpr int QB = 256, BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256, NST = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 slots][K 16 KiB | V 16 KiB][key-valid bits: 8 B per key tile]
+  const int l = threadIdx.x & 63, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int qblk, b, hq;
+  attn_work_item(blockIdx.x, (a.Sq + QB - 1) / QB, a.B, a.Hq, a.Hkv, a.causal != 0, qblk, b, hq);
+  const int hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = qblk * QB + w * 32;
+  const int qi = q0 + (l & 31);
+  const int shift = a.Skv - a.Sq;
+  const bf16* Q = (const bf16*)a.q + b * a.q_sb + hq * a.q_sh;
+  const SRsrc rk = rows_rsrc((const bf16*)a.k + b * a.k_sb + hkv * a.k_sh, a.Skv, a.k_ss);
+  const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const ImgaBases bases = imga_bases(smem, TILE);
+
+  bf16x8 qf[NDS];
+  {
+    const bf16* qrow = qi < a.Sq ? Q + (int64_t)qi * a.q_ss : nullptr;
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) qf[ds] = row_frag_global(qrow, ds);
+  }
+  f32x16 o_acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc = a.scale * LOG2E;
+
+  int ntiles = (a.Skv + BKV - 1) / BKV;
+  if (a.causal) {
+    const int qmax = min(a.Sq - 1, qblk * QB + QB - 1) + shift;
+    ntiles = qmax < 0 ? 0 : min(ntiles, qmax / BKV + 1);
+  }
+  // Key-valid bits (inside Skv and not masked out) of every tile, built once: a global load of the key mask INSIDE the tile
+  // loop makes hipcc put `s_waitcnt vmcnt(0)` at the join in front of the first QK^T product, which drains the K/V DMA an
+  // issuing wave requested a few instructions earlier (its whole latency exposed on every tile, on every SIMD).
+  unsigned long long* kvbits = (unsigned long long*)(smem + NST * 2 * TILE);
+  for (int t = w; t < ntiles; t += 8) {
+    bool kvalid = (t * BKV + l) < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + t * BKV + l] != 0;
+    const unsigned long long bits = __ballot(kvalid);
+    if (l == 0) kvbits[t] = bits;
+  }
+  // ... and for the same reason the Q fragments are consumed once HERE: hipcc then waits for their loads now, not with a
+  // `vmcnt(0)` in front of the first product of every tile
+#pragma unroll
+  for (int ds = 0; ds < NDS; ++ds) asm volatile("" ::"v"(qf[ds]));
+  unsigned lk[2], lv[2];
+  imga_lane_patterns(lk, lv, a.k_ss, a.v_ss);
+  auto issue = [&](int t) {
+    if (MM_QDIAG & 1) return;
+    imga_issue_kv(w, lds0 + (unsigned)((t & (NST - 1)) * 2 * TILE), t * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
+  };
+  // wave-uniform: the tile exists, this wave has rows, and the tile is not wholly above the wave's causal diagonal
+  auto active = [&](int t) { return t < ntiles && q0 < a.Sq && !(a.causal && t * BKV > q0 + 31 + shift); };
+
+  // state handed from S(t) to softmax(t) (for the early half: across a barrier)
+  f32x16 s_acc[2];
+  unsigned long long kbits = 0;
+  bool need_mask = false;
+
+  auto seg_s = [&](int t) {           // S^T = K(t) . Q^T: 16 MFMAs, K fragment i+3 requested before MFMA i
+    const int kv0 = t * BKV, so = (t & (NST - 1)) * 2 * TILE;
+    {
+      const u32x2 kv = *(const u32x2*)(kvbits + t);                 // same address in every lane (LDS broadcast)
+      kbits = (unsigned long long)__builtin_amdgcn_readfirstlane(kv[0]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(kv[1]) << 32);
+    }
+    need_mask = (kbits != ~0ull) || (a.causal && (kv0 + BKV - 1) > (q0 + shift));
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bf16x8 kf[RD];
+#pragma unroll
+    for (int j = 0; j < RD - 1; ++j) kf[j] = (MM_QDIAG & 16) ? qf[j & 7] : imga_kfrag(bases, so, 0, j);
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i + RD - 1 < 16 && !(MM_QDIAG & 16)) kf[(i + RD - 1) % RD] = imga_kfrag(bases, so, (i + RD - 1) >> 3, (i + RD - 1) & 7);
+      // the first product of each chain takes C = 0 as an inline constant (no 32-register clear per tile)
+      if (!(MM_QDIAG & 4)) s_acc[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RD], qf[i & 7], (i & 7) ? s_acc[i >> 3] : zero16, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
+  };
+
+  auto seg_softmax_pv = [&](int t) {  // mask, online softmax, O rescale, then O^T += V(t)^T . P^T: 16 MFMAs
+    const int kv0 = t * BKV, so = (t & (NST - 1)) * 2 * TILE;
+    bf16x8 vf[RD];                                                   // first V^T fragments travel under the softmax
+#pragma unroll
+    for (int j = 0; j < RD - 1; ++j) vf[j] = (MM_QDIAG & 16) ? qf[j & 7] : imga_vfrag(bases, so, j >> 2, j & 3);
+    if (need_mask) {
+      const unsigned long long kb2 = kbits >> (4 * h);
+      const int dlim = a.causal ? (qi + shift - kv0 - 4 * h) : 0x7fffffff;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = kb * 32 + (r & 3) + 8 * (r >> 2);
+          const bool ok = ((kb2 >> c) & 1ull) && c <= dlim;
+          s_acc[kb][r] = ok ? s_acc[kb][r] : -INFINITY;
+        }
+    }
+    bf16x8 pf[2][2];
+    if (MM_QDIAG & 2) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (bf16)s_acc[kb][r];
+    } else {
+    const float mx = swap32_max(rowmax32(s_acc[0], s_acc[1])) * sc;
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    // packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction, same IEEE results): the softmax is the longer
+    // of the kernel's two pipes, so instruction count is time here
+    f32x2 rs2 = {0.f, 0.f};
+    const f32x2 sc2 = {sc, sc}, nm2 = {-m_safe, -m_safe};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sv = {s_acc[kb][r], s_acc[kb][r + 1]};
+        const f32x2 t2 = __builtin_elementwise_fma(sv, sc2, nm2);
+        f32x2 p2;
+        p2[0] = __builtin_amdgcn_exp2f(t2[0]);
+        p2[1] = __builtin_amdgcn_exp2f(t2[1]);
+        rs2 += p2;
+        pf[kb][r >> 3][r & 7] = (bf16)p2[0];
+        pf[kb][r >> 3][(r & 7) + 1] = (bf16)p2[1];
+      }
+    const float rs = rs2[0] + rs2[1];
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                                   // i = db * 4 + ks
+      if (i + RD - 1 < 16 && !(MM_QDIAG & 16)) vf[(i + RD - 1) % RD] = imga_vfrag(bases, so, (i + RD - 1) >> 2, (i + RD - 1) & 3);
+      if (!(MM_QDIAG & 8)) o_acc[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % RD], pf[(i >> 1) & 1][i & 1], o_acc[i >> 2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
+  };
+
+  if ((a.prio == 2 && w >= 4) || (a.prio == 3 && w < 4)) __builtin_amdgcn_s_setprio(1);
+  if (w < 4) {
+    // ---- late half: DMA duty.  An issuing wave has 8 pieces per tile in flight.
+    if (ntiles > 0) issue(0);
+    if (ntiles > 1) issue(1);
+    if (ntiles > 2) issue(2);
+    if (ntiles > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // tile 0 has landed (the early half reads it
+    else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // right after the opening barrier)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int k = 0; k < ntiles; ++k) {
+      if (k + 2 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // tile k+1 has landed: the early half reads its
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // K in this interval
+      __builtin_amdgcn_s_barrier();
+      if (k + 3 < ntiles) issue(k + 3);
+      if (active(k)) {
+        seg_s(k);
+        seg_softmax_pv(k);
+      }
+    }
+  } else {
+    // ---- early half: its barrier sits between S(k) and softmax(k)
+    __builtin_amdgcn_s_barrier();
+    bool act = active(0);
+    if (act) seg_s(0);
+    for (int k = 0; k < ntiles; ++k) {
+      __builtin_amdgcn_s_barrier();
+      if (act) seg_softmax_pv(k);
+      act = active(k + 1);
+      if (act) seg_s(k + 1);
+    }
+  }
+  const float l_tot = swap32_sum(l_run);
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (qi < a.Sq) {
+    bf16* orow = (bf16*)a.out + (((int64_t)b * a.Sq + qi) * a.Hq + hq) * 128;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(o_acc[db][rg * 4 + e] * inv);
+        *(bf16x4*)(orow + db * 32 + 8 * rg + 4 * h) = o;
+      }
+    if (h == 0) a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : INFINITY;
+  }
+}
+
 // dK/dV for D = 128: 4 waves x 32 keys, TWO workgroups per CU.  Register diet that makes 2 waves/SIMD fit: V fragments
 // come from an LDS image of the workgroup's 128 keys (not registers) and the Q / dO tiles arrive by LDS-DMA (no staging
 // registers) into a 2-deep ring, one barrier per query tile.
@@ -2093,6 +2313,10 @@ __global__ void attn_decode_merge_kernel(const float* ws, int nsplit, bf16* out)
 
 int g_attn_fwd_waves = 8;     // waves per workgroup of the D=128 forward (mm_set_option "attn_fwd_waves": 8 or 4)
 int g_attn_fwd_pf = 1;        // D=128 forward with prefetched fragments (attn_fwd128p_kernel; mm_set_option "attn_fwd_pf" 0 = the older kernel)
+int g_attn_fwd_q = 1;         // D=128 forward with the two waves of a SIMD out of phase (attn_fwd128q_kernel; "attn_fwd_q" 0 = attn_fwd128p_kernel)
+int g_attn_q_rd = 4;          // fragment ring depth of attn_fwd128q_kernel ("attn_q_rd": 4, 6 or 8)
+int g_attn_diag = 0;          // AttnArgs::diag ("attn_diag")
+int g_attn_q_prio = 1;        // s_setprio policy of the out-of-phase kernels (AttnArgs::prio; "attn_q_prio")
 int g_attn_dkv_pair = 1;      // balanced paired dK/dV kernel (mm_set_option "attn_dkv_pair"; 0 = one key block per workgroup)
 int g_attn_issue_waves = 4;   // waves issuing the K/V DMA in the 8-wave D=128 kernels (mm_set_option "attn_issue_waves")
 
@@ -2103,6 +2327,23 @@ static bool attn_use_v1() {
 
 template <int D>
 int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
+  if (D == 128 && !attn_use_v1() && g_attn_fwd_pf && g_attn_fwd_q && g_attn_fwd_waves == 8 && a.Skv <= 256 * 1024) {
+    const size_t lds = 4 * 2 * 64 * 256 + (size_t)((a.Skv + 63) / 64) * 8;       // K/V ring + key-valid bits
+    const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;
+    if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+    if (g_attn_q_rd == 8) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd128q_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_fwd128q_kernel<8>, dim3((unsigned)nwg), dim3(512), lds, s, a);
+    } else if (g_attn_q_rd == 6) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd128q_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_fwd128q_kernel<6>, dim3((unsigned)nwg), dim3(512), lds, s, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)attn_fwd128q_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(attn_fwd128q_kernel<4>, dim3((unsigned)nwg), dim3(512), lds, s, a);
+    }
+    MM_CHECK_LAUNCH();
+    return MM_OK;
+  }
   if (D == 128 && !attn_use_v1() && g_attn_fwd_pf && g_attn_fwd_waves == 8) {
     const size_t lds = 3 * 2 * 64 * 256;
     const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;
@@ -2189,6 +2430,10 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
 int mm_attn_option(const char* name, int value) {   // reached through mm_set_option (mm_gemm.hip)
   if (!strcmp(name, "attn_dkv_pair")) { g_attn_dkv_pair = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_fwd_pf")) { g_attn_fwd_pf = value != 0; return MM_OK; }
+  if (!strcmp(name, "attn_fwd_q")) { g_attn_fwd_q = value != 0; return MM_OK; }
+  if (!strcmp(name, "attn_q_prio")) { g_attn_q_prio = value; return MM_OK; }
+  if (!strcmp(name, "attn_q_rd")) { g_attn_q_rd = value; return MM_OK; }
+  if (!strcmp(name, "attn_diag")) { g_attn_diag = value; return MM_OK; }
   if (!strcmp(name, "attn_fwd_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_attn_fwd_waves = value; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -2215,6 +2460,8 @@ extern "C" int mm_attn_fwd(int dtype, const void* q, const void* k, const void* 
   if (!q || !k || !v || !out || !lse) return MM_ERR_ARG;
   if (B == 0 || Sq == 0) return MM_OK;
   AttnArgs a{};
+  a.prio = g_attn_q_prio;
+  a.diag = g_attn_diag;
   a.q = q; a.k = k; a.v = v; a.B = B; a.Sq = Sq; a.Skv = Skv; a.Hq = Hq; a.Hkv = Hkv;
   a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh; a.v_sb = v_sb; a.v_ss = v_ss; a.v_sh = v_sh;
   a.kmask = key_mask; a.causal = causal; a.scale = scale; a.out = out; a.lse = lse;
@@ -2240,6 +2487,8 @@ extern "C" int mm_attn_bwd(int dtype, const void* q, const void* k, const void* 
   if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !delta) return MM_ERR_ARG;
   if (B == 0 || Sq == 0) return MM_OK;
   AttnArgs a{};
+  a.prio = g_attn_q_prio;
+  a.diag = g_attn_diag;
   a.q = q; a.k = k; a.v = v; a.B = B; a.Sq = Sq; a.Skv = Skv; a.Hq = Hq; a.Hkv = Hkv;
   a.q_sb = q_sb; a.q_ss = q_ss; a.q_sh = q_sh; a.k_sb = k_sb; a.k_ss = k_ss; a.k_sh = k_sh; a.v_sb = v_sb; a.v_ss = v_ss; a.v_sh = v_sh;
   a.kmask = key_mask; a.causal = causal; a.scale = scale; a.out = (void*)out; a.lse = (float*)lse;

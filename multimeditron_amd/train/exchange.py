@@ -1,6 +1,8 @@
 """Bucketed gradient all-reduce over a flat gradient buffer, launched from inside backward.
 
-Pure torch.distributed (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests); no kernels here.
+Transport: torch.distributed (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests) by default, or the
+C-ABI communicator (`comm=RcclComm`, train/comm.py -> mm_comm_allreduce_bucket) when the trainer is started with
+MM_COMM=abi / abi-rsag; no kernels here.
 The flat trainable ranges are cut into buckets (default 256 MiB of bf16: large enough to run RCCL at link rate, small
 enough that the first bucket leaves while the decoder is still back-propagating).  A bucket is launched the moment the
 LAST expected gradient write of every parameter that overlaps it has been enqueued; `async_op=True` puts the collective
@@ -28,10 +30,12 @@ class _Bucket:
 
 class GradExchanger:
     def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], segments: Sequence[Tuple[int, int, int]],
-                 bucket_elems: int, dist=None, group=None, force: bool = False):
-        """ranges: trainable [start,end) of flat_grad; segments: (param_key, start, end) for every trainable param."""
+                 bucket_elems: int, dist=None, group=None, force: bool = False, comm=None):
+        """ranges: trainable [start,end) of flat_grad; segments: (param_key, start, end) for every trainable param.
+        comm: an `RcclComm` to carry the buckets instead of dist.all_reduce (dist stays the control channel)."""
         self.grad = flat_grad
         self.dist, self.group = dist, group
+        self.comm = comm
         self.world = dist.get_world_size(group) if dist is not None else 1
         self.force = force
         self.buckets: List[_Bucket] = []
@@ -91,6 +95,9 @@ class GradExchanger:
                 self.launched_early += 1
 
     def _launch(self, bk: _Bucket):
+        if self.comm is not None:
+            bk.work = self.comm.all_reduce(self.grad[bk.start:bk.end])
+            return
         bk.work = self.dist.all_reduce(self.grad[bk.start:bk.end], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish_step(self):

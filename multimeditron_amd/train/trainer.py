@@ -245,8 +245,17 @@ class MultimodalTrainer:
         self._trainable = [seg for seg in flat.segments if seg.param.requires_grad]
         import os
         force = bool(os.environ.get("MM_FORCE_EXCHANGE")) and self.dist is not None    # rehearse RCCL calls with 1 rank
+        # transport of the buckets: torch.distributed's all_reduce (default) or the C-ABI communicator (train/comm.py)
+        self.comm = None
+        mode = os.environ.get("MM_COMM", "")
+        if mode in ("abi", "abi-rsag") and (self.world > 1 or force) and flat.grad.is_cuda:
+            from .comm import RcclComm
+            self.comm = RcclComm(self.dist, self.pg, algo=1 if mode == "abi-rsag" else 0)
+        elif mode not in ("", "torch"):
+            raise ValueError(f"MM_COMM={mode!r}: expected 'torch', 'abi' or 'abi-rsag'")
         self.exchanger = GradExchanger(flat.grad, [(s, e) for s, e, _ in self.ranges], segs, self.bucket_elems,
-                                       dist=self.dist if (self.world > 1 or force) else None, group=self.pg, force=force)
+                                       dist=self.dist if (self.world > 1 or force) else None, group=self.pg, force=force,
+                                       comm=self.comm)
         if self.world > 1 and not os.environ.get("MM_GEMM_PERSIST"):
             # The GEMM's persistent grid is one resident workgroup per CU, each walking 1/256 of the tiles.  While an RCCL
             # kernel holds some CUs (its waves and an 8-wave GEMM workgroup do not fit one CU together), the workgroups that
@@ -458,6 +467,9 @@ class MultimodalTrainer:
                 del seg.param._mm_ss
         self.master = self.m = self.v = self._norm_partial = self._ss = None
         self._blocks = []
+        if getattr(self, "comm", None) is not None:
+            self.comm.close()
+            self.comm = self.exchanger.comm = None
 
     # ------------------------------------------------------------------ checkpoints (reference cli/train.py:186-195)
     def save_model(self, path: str, **kw):

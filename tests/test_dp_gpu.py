@@ -90,3 +90,77 @@ def test_dp2_equals_grad_accumulation(tmp_path):
         ref = p.detach().float().cpu()
         err = float((torch.from_numpy(dp_params[k]) - ref).norm() / (ref.norm() + 1e-12))
         assert err < 1e-4, (k, err)
+
+
+def _abi_rank(port, tmp, q):
+    """One rank driving RCCL through the C-ABI communicator (mm_comm_*): a 1-rank sum is the identity, so every result is
+    known exactly; what is exercised is the binding, the stream/event ordering and the bucket plumbing."""
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MM_FORCE_EXCHANGE="1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        from multimeditron_amd.train.comm import RcclComm
+        from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
+        from tests.model_utils import to_device
+        res = {}
+        for algo in (0, 1):
+            c = RcclComm(dist, None, algo=algo)
+            for dtype in (torch.bfloat16, torch.float32):
+                x = torch.randn(1_000_003, device="cuda").to(dtype)            # odd count: the tail path of algo 1
+                y = x.clone() * 3                                              # a producer on the compute stream the comm stream must wait for
+                ref = y.clone()
+                c.all_reduce(y).wait()
+                z = ref.clone()[:1_000_000]
+                c.reduce_scatter(z).wait()
+                c.all_gather(z).wait()
+                torch.cuda.synchronize()
+                res[(algo, str(dtype))] = bool(torch.equal(y, ref)) and bool(torch.equal(z, ref[:1_000_000]))
+            c.close()
+        params = {}
+        for mode in ("torch-none", "abi", "abi-rsag"):
+            if mode == "torch-none":
+                os.environ.pop("MM_COMM", None)
+                os.environ.pop("MM_FORCE_EXCHANGE", None)
+            else:
+                os.environ.update(MM_COMM=mode, MM_FORCE_EXCHANGE="1")
+            model, v, R = _build(os.path.join(tmp, mode), "bfloat16")
+            tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=1e-3, betas=(0.9, 0.95), max_grad_norm=1.0,
+                                   bucket_mb=1)
+            early = []
+            for name in ("right", "interleaved4", "left"):
+                tr.training_step(to_device(R.golden_batch(v, name)))
+                early.append(tr.exchanger.launched_early)
+            tr.synchronize()
+            torch.cuda.synchronize()
+            params[mode] = ({k: p.detach().float().cpu().numpy() for k, p in model.named_parameters()}, early,
+                            type(tr.exchanger.comm).__name__)
+            tr.close()
+        q.put(("ok", res, params))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("fail: " + traceback.format_exc()[-2500:], None, None))
+
+
+def test_c_abi_communicator_single_rank(tmp_path):
+    """mm_comm_* (RCCL behind the C-ABI): collectives on a 1-rank communicator leave the data bit-identical, and a trainer whose
+    buckets travel through it (launched from inside backward, on the communicator's stream) ends with the same parameters,
+    bit for bit, as one that exchanges nothing."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_abi_rank, args=(_free_port(), str(tmp_path), q))
+    p.start()
+    status, res, params = q.get(timeout=240)
+    p.join(timeout=60)
+    assert status == "ok", status
+    assert all(res.values()), res
+    base = params["torch-none"][0]
+    for mode in ("abi", "abi-rsag"):
+        got, early, kind = params[mode]
+        assert kind == "RcclComm"
+        assert early[0] == 0 and early[1] > 0 and early[2] > 0, early
+        for k in base:
+            assert (got[k] == base[k]).all(), (mode, k)

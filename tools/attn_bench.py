@@ -34,7 +34,21 @@ def run(B, S, Hq, Hkv, D, causal, mask=False):
     print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} D={D} causal={causal} mask={mask}: fwd {tf:.3f} ms ({f / tf / 1e9:.0f} TF/s)  bwd {tb:.3f} ms ({2.5 * f / tb / 1e9:.0f} TF/s algorithmic)", flush=True)
 
 
-from multimeditron_amd._lib import lib
+from multimeditron_amd._lib import lib as _rawlib
+
+
+class _Checked:
+    """mm_set_option with its return code checked (an unknown switch means the library is older than this script)."""
+    def mm_set_option(self, name, value):
+        rc = _rawlib().mm_set_option(name, value)
+        assert rc == 0, (name, value, rc)
+        return rc
+
+
+def lib():
+    return _Checked()
+
+
 if "--ab-pair" in sys.argv:      # dK/dV: one key block per workgroup vs the balanced paired kernel (same process)
     for v in (0, 1, 0, 1):
         lib().mm_set_option(b"attn_dkv_pair", v)
@@ -59,6 +73,41 @@ if "--ab-pf" in sys.argv:        # D=128 forward: serialized fragment reads vs t
     run(2, 4096, 32, 8, 128, True)
     run(4, 2048, 28, 4, 128, True)
     run(4, 2048, 32, 8, 128, True, mask=True)
+    sys.exit(0)
+if "--ab-q" in sys.argv:         # D=128 forward: waves of a SIMD in phase (p kernel) vs out of phase (q kernel), interleaved
+    B, S, Hq, Hkv, D = 2, 1000, 8, 2, 128            # bit-identity first (ragged length, key mask with holes)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q = torch.randn(B, S, Hq, D, device="cuda", generator=g).to(torch.bfloat16)
+    k = torch.randn(B, S, Hkv, D, device="cuda", generator=g).to(torch.bfloat16)
+    v = torch.randn(B, S, Hkv, D, device="cuda", generator=g).to(torch.bfloat16)
+    km = (torch.rand(B, S, device="cuda", generator=g) > 0.1).long()
+    for causal in (True, False):
+        for mask in (None, km):
+            outs = []
+            for qv in (0, 1):
+                lib().mm_set_option(b"attn_fwd_q", qv)
+                o, lse = K.attn_fwd(q, k, v, mask, causal, D ** -0.5)
+                outs.append((o.clone(), lse.clone()))
+            print("fwd p vs q (row sums taken pairwise in q: last-bit differences):", causal, mask is not None, "max |dO|", float((outs[0][0].float() - outs[1][0].float()).abs().max()), "max |dlse|", float((outs[0][1] - outs[1][1]).abs().max()), flush=True)
+    run(4, 2048, 32, 8, 128, True)
+    for v_, pr, rd in ((0, 0, 4), (1, 1, 4), (1, 1, 6), (1, 1, 8), (1, 0, 8), (0, 0, 4), (1, 1, 4), (1, 1, 6), (1, 1, 8), (1, 0, 8)):
+        lib().mm_set_option(b"attn_fwd_q", v_)
+        lib().mm_set_option(b"attn_q_prio", pr)
+        lib().mm_set_option(b"attn_q_rd", rd)
+        print("attn_fwd_q", v_, "prio", pr, "rd", rd)
+        run(4, 2048, 32, 8, 128, True)
+    lib().mm_set_option(b"attn_q_prio", 1)
+    run(2, 4096, 32, 8, 128, True)
+    run(4, 2048, 28, 4, 128, True)
+    run(4, 2048, 32, 8, 128, True, mask=True)
+    sys.exit(0)
+if "--diag-q" in sys.argv:       # timing experiments on the out-of-phase forward (wrong results by design)
+    lib().mm_set_option(b"attn_q_prio", 1)
+    run(4, 2048, 32, 8, 128, True)
+    for d in (0, 1, 2, 4, 8, 16, 4 | 8, 2 | 16, 1 | 16, 1 | 2 | 16, 4 | 8 | 16 | 1, 0):
+        lib().mm_set_option(b"attn_diag", d)
+        print("diag", d)
+        run(4, 2048, 32, 8, 128, True)
     sys.exit(0)
 if "--quick" in sys.argv:
     run(4, 2048, 32, 8, 128, True)

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; defs=$2
 mkdir -p build_diag/obj_$name
 objs=""
-for f in mm_gemm mm_attn mm_rowwise mm_embed mm_optim mm_debug; do
+for f in mm_gemm mm_attn mm_rowwise mm_embed mm_optim mm_debug mm_comm; do
   o=multimeditron_amd/csrc/build/$f.o
   if [ $f = mm_gemm ] || [ $f = mm_attn ]; then
     o=build_diag/obj_$name/$f.o
@@ -15,5 +15,5 @@ for f in mm_gemm mm_attn mm_rowwise mm_embed mm_optim mm_debug; do
   objs="$objs $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_diag/libmmhip_$name.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_diag/libmmhip_$name.so $objs -ldl
 echo build_diag/libmmhip_$name.so
