@@ -1243,7 +1243,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128q_kernel(AttnArgs a) {
     const int kv0 = t * BKV, so = (t & (NST - 1)) * 2 * TILE;
     {
       const u32x2 kv = *(const u32x2*)(kvbits + t);                 // same address in every lane (LDS broadcast)
-      kbits = (unsigned long long)__builtin_amdgcn_readfirstlane(kv[0]) | ((unsigned long long)__builtin_amdgcn_readfirstlane(kv[1]) << 32);
+      kbits = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(kv[0]) |
+              ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(kv[1]) << 32);     // (unsigned): the builtin returns int
     }
     need_mask = (kbits != ~0ull) || (a.causal && (kv0 + BKV - 1) > (q0 + shift));
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
