@@ -1,18 +1,21 @@
 // GEMM for every linear layer on the path (forward, input-gradient, weight-gradient).
 //
-// bf16 path: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Operands are staged HBM -> registers -> LDS with
-// 16-byte accesses and one barrier per K-step (double-buffered LDS, next tile's global loads issued
-// before the current tile's MFMAs).  Two LDS images, chosen per operand by how it lies in memory:
+// bf16, the kernel the step runs (gemm_bf16_dma_kernel): 256x256x64 block tile, 8 waves (2x4), each wave 128x64 = 8x4 tiles of
+// v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Operands stream HBM -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, inline asm)
+// into a 2-deep ring with ONE raw s_barrier per K-tile; per-lane DMA offsets are loop-invariant (the K-step enters through the
+// instruction's SGPR soffset); workgroups are persistent (one per CU, tiles in an XCD-aware order, GROUP_M = 8) and the last,
+// half-empty round of tiles is cut into 256x128 halves.  Smaller instantiations (128x128, 64x128) serve problems that do not
+// fill 256 CUs with 256-wide tiles (ViT-L on 4 images, the projector); gemm_bf16_kernel (128x128, register-staged, 2
+// workgroups per CU) remains for mid-sized problems and for operands whose byte offsets exceed 32 bits; gemm_skinny_kernel
+// (M <= 16) streams the weights once for the decode step.
+// Two LDS images, chosen per operand by how it lies in memory:
 //   KC (K contiguous, global [X][K])  image [x][k] swizzled  fragments by ds_read_b128 (conflict free)
-//   KS (K strided,    global [K][X])  image [k][x] swizzled  fragments by 2x ds_read_b64_tr_b16
+//   KS (K strided,    global [K][X])  image [k][x] rotated   fragments by 2x ds_read_b64_tr_b16
 // so NT / NN / TN need no transposed copy of any tensor.  The MFMA is issued with swapped operands
-// (D^T = B^T A^T) so each lane owns 4 consecutive output columns -> 8-byte stores, and bias /
-// activation / residual / accumulate are applied in registers.
+// (D^T = B^T A^T) so each lane owns 4 consecutive output columns -> 8-byte stores, and bias / activation / residual /
+// accumulate / SwiGLU (forward: gate|up tile pairs; backward: on the down_proj dgrad) are applied in registers.
 // Out-of-range rows are handled by buffer loads (hardware bounds check returns 0), so M, N need no
 // padding and K only has to be a multiple of 8 for K-contiguous operands.
-// Workgroup ids are remapped XCD-aware (bijective) and grouped along M so one XCD's L2 holds the
-// A/B panels its concurrent workgroups share.
 //
 // f32 path (parity only): 64x64x16 tiles on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include <stdlib.h>
