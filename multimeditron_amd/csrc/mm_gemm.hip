@@ -947,10 +947,13 @@ static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA
 extern "C" int mm_attn_set_issue_waves(int v);
 int mm_attn_option(const char* name, int value);
 
+extern int g_adamw_blocks;    // mm_optim.hip
+
 extern "C" int mm_set_option(const char* name, int value) {
   if (!name) return MM_ERR_ARG;
   if (!strcmp(name, "attn_issue_waves")) return mm_attn_set_issue_waves(value);
   if (!strncmp(name, "attn_", 5)) return mm_attn_option(name, value);
+  if (!strcmp(name, "adamw_blocks")) { if (value < 0) return MM_ERR_ARG; g_adamw_blocks = value; return MM_OK; }
   if (!strcmp(name, "gemm_tail")) { g_opt_tail = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_skinny")) { g_opt_skinny = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_small")) { if (value < -1 || value > 5) return MM_ERR_ARG; g_opt_small = value; return MM_OK; }

@@ -116,6 +116,8 @@ extern "C" int mm_gradnorm_finish(const float* partial, int nblk, float max_norm
   return MM_OK;
 }
 
+int g_adamw_blocks = 0;       // mm_set_option "adamw_blocks": grid cap of the update kernel (0 = MM_ADAMW_BLOCKS or 2048)
+
 extern "C" int mm_adamw_step(int dtype, void* p, const void* g, float* master, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, const float* clip, void* stream) {
   if (!p || !g || !master || !m || !v || n < 0 || step < 1) return MM_ERR_ARG;
@@ -125,7 +127,8 @@ extern "C" int mm_adamw_step(int dtype, void* p, const void* g, float* master, f
   const int64_t nv4 = (n / 4 + 255) / 256;
   // grid cap: the update runs on a side stream under the next step's forward; MM_ADAMW_BLOCKS throttles how much of the
   // chip (and of HBM) it takes while the forward's GEMMs run
-  static const int64_t cap = [] { const char* e = getenv("MM_ADAMW_BLOCKS"); const long c = e ? atol(e) : 0; return (int64_t)(c > 0 ? c : 2048); }();
+  static const int64_t env_cap = [] { const char* e = getenv("MM_ADAMW_BLOCKS"); const long c = e ? atol(e) : 0; return (int64_t)(c > 0 ? c : 2048); }();
+  const int64_t cap = g_adamw_blocks > 0 ? g_adamw_blocks : env_cap;
   const unsigned nb = (unsigned)(nv4 < 1 ? 1 : (nv4 < cap ? nv4 : cap));
   static const bool nt = [] { const char* e = getenv("MM_ADAMW_NT"); return !e || e[0] != '0'; }();
   hipStream_t st = (hipStream_t)stream;

@@ -328,6 +328,7 @@ class MultimodalTrainer:
         event, and the compute stream waits for the last event before the next backward writes gradients."""
         import re
         self._blocks = []          # [(module or None, [(start, end, decay, state_off)])] in forward order
+        self._defer_from, self._deferred = None, None
         if not self.overlap_optimizer:
             return
         state_off = {}
@@ -347,6 +348,11 @@ class MultimodalTrainer:
         groups: Dict[str, List] = {}
         for seg in self._trainable:
             groups.setdefault(block_key(seg.name), []).append(seg)
+        # MM_ADAMW_DEFER=1 (default off, measured slower): the decoder's blocks are not launched with the rest at the end of
+        # the step but when the NEXT forward reaches the first decoder layer -- see _launch_deferred
+        defer = os.environ.get("MM_ADAMW_DEFER", "0") == "1"
+        self._defer_from: Optional[int] = None
+        self._deferred = None
 
         def order(key):    # forward order: modality towers (embeddings, pre-norm, layers, projector), then the LLM
             llm = key.startswith("model.")
@@ -368,6 +374,8 @@ class MultimodalTrainer:
                 else:
                     runs.append([sg.start, end, sg.decay])
             self._blocks.append((self._hook_module(key), [(a, b, d, st_off(a)) for a, b, d in runs]))
+            if self._defer_from is None and defer and order(key)[0] >= 11 and self._blocks[-1][0] is not None:
+                self._defer_from = len(self._blocks) - 1            # first decoder layer: see _launch_deferred
         covered = sum(b - a for _, rs in self._blocks for a, b, _, _ in rs)
         assert covered == sum(e - s0 for s0, e, _ in self.ranges), "optimizer pipeline must cover every trainable range"
         self._opt_stream = torch.cuda.Stream()
@@ -375,6 +383,7 @@ class MultimodalTrainer:
         self._all_done: Optional[torch.cuda.Event] = None
         self._hooks = []
         self._unfired: List[int] = []
+        self._deferred_mods = set() if self._defer_from is None else {id(m) for m, _ in self._blocks[self._defer_from:] if m is not None}
         hooked = set()
         for mod, _ in self._blocks:
             if mod is not None and id(mod) not in hooked:      # several blocks may share one call site (ViT embeddings.*)
@@ -396,13 +405,50 @@ class MultimodalTrainer:
             key = key.rsplit(".", 1)[0] if "." in key else ""
         return None
 
+    def _launch_deferred(self):
+        """MM_ADAMW_DEFER=1 (an experiment that LOST; off by default): the decoder's share of the update (97 % of the
+        parameters, 43 ms of HBM streaming) launched from the NEXT forward at the moment its host code reaches the first decoder
+        layer, ordered after everything the compute stream has been given so far, instead of at the end of the step.
+        Motivation: a kernel trace (tools/stream_time.py) shows that AdamW's 2048 grid-striding workgroups, launched at the end
+        of the step, fill every wave slot while the next step's ViT forward runs: each of the ViT's ~350 short kernels waits
+        for slots (attention 402 us instead of 11, GELU 277 instead of 9, LayerNorm 134 instead of 12): 33 ms on the compute
+        stream for 5 ms of work.  Measured (tools/step_ab.py, same process): 401.6 ms/step deferred vs 394.2 as is.  Beside the
+        decoder's GEMMs the update costs MORE: the 256x256 GEMM's LDS-DMA stream shares HBM with 5 TB/s of optimizer traffic and
+        loses about 0.8 ms per ms of update, wherever the update is placed; the ViT forward, being launch-latency-bound, is the
+        cheapest thing to run it beside.  (A smaller update grid, `mm_set_option("adamw_blocks", 512)`: 388.6-393.8 vs 394.2,
+        inside the noise.)  The update therefore costs the step about 35 of its 44 ms on this chip; fewer bytes per parameter
+        (28 now) is what would lower it."""
+        upd = self._deferred
+        if upd is None:
+            return
+        self._deferred = None
+        main, side = torch.cuda.current_stream(), self._opt_stream
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        side.wait_event(ev0)
+        with torch.cuda.stream(side):
+            for mod, runs in self._blocks[self._defer_from:]:
+                for s, e, decay, off in runs:
+                    upd(s, e, decay, off)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                if mod is not None:
+                    self._pending[id(mod)] = ev
+            self._all_done = ev
+        if any(mod is None for mod, _ in self._blocks[self._defer_from:]):
+            main.wait_event(self._all_done)
+
     def _wait_block(self, mod, _inputs):
+        if self._deferred is not None and id(mod) in self._deferred_mods:
+            self._launch_deferred()
         ev = self._pending.pop(id(mod), None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
     def _wait_optimizer(self):
         """Everything the side stream still owes (before gradients are overwritten or parameters read ad hoc)."""
+        if getattr(self, "_deferred", None) is not None:
+            self._launch_deferred()                           # no forward reached the decoder since the last step
         if getattr(self, "_all_done", None) is not None:
             # blocks whose hook did not fire in the forward that just ran (legitimate for a tower the batch never entered;
             # a bug if forward read them: tests/test_trainer_gpu.py checks this list is empty for an image batch)
@@ -436,8 +482,10 @@ class MultimodalTrainer:
         main = torch.cuda.current_stream()
         side = self._opt_stream
         side.wait_stream(main)                               # gradients (and their all-reduce) are complete
+        now = self._blocks if self._defer_from is None else self._blocks[:self._defer_from]
         with torch.cuda.stream(side):
-            for mod, runs in self._blocks:
+            ev = None
+            for mod, runs in now:
                 for s, e, decay, off in runs:
                     upd(s, e, decay, off)
                 ev = torch.cuda.Event()
@@ -446,8 +494,10 @@ class MultimodalTrainer:
                     self._pending[id(mod)] = ev
             self._all_done = ev
         # blocks without a hookable module: wait for them right away
-        if any(mod is None for mod, _ in self._blocks):
+        if ev is not None and any(mod is None for mod, _ in now):
             main.wait_event(self._all_done)
+        if self._defer_from is not None:
+            self._deferred = upd                              # the decoder's blocks: launched by the next forward (_launch_deferred)
 
     def synchronize(self):
         """Make the compute stream wait for the in-flight optimiser update (call before reading parameters)."""

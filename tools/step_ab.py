@@ -39,6 +39,8 @@ def endless():
         yield host_batch
 
 
+OPTION_DEFAULTS = {"adamw_blocks": 0, "attn_q_rd": 4, "attn_q_prio": 1, "attn_diag": 0, "gemm_kernel": 0, "gemm_small": -1,
+                   "gemm_issue_waves": 4, "attn_issue_waves": 4, "attn_fwd_waves": 8}      # everything else is an on/off switch, default 1
 res = {v: [] for v in args.variants}
 for r in range(args.rounds):
     for v in args.variants:
@@ -70,8 +72,8 @@ for r in range(args.rounds):
         del tr, feed
         import gc
         gc.collect()
-        for k in opts:                          # switches default to 1 in this tool's use
-            lib().mm_set_option(k.encode(), 1)
+        for k in opts:                          # back to the library's default
+            lib().mm_set_option(k.encode(), OPTION_DEFAULTS.get(k, 1))
         for k, val in saved.items():
             if val is None:
                 os.environ.pop(k, None)
