@@ -1697,7 +1697,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
   float* red = (float*)(smem + 2 * IMG);                               // 64 KiB = both rings, reused for the team sum
   float* rowc = (float*)(smem + 2 * IMG + 8 * QT) + team * 128;        // per team [2 stages][lse*log2e (32) | delta (32)]
   const int b = blockIdx.z, hkv = blockIdx.y;
-  const int G = a.Hq / a.Hkv, GH = G / 2;
+  const int G = a.Hq / a.Hkv;
   const int nkb = (a.Skv + 127) / 128;
   const int shift = a.Skv - a.Sq;
   const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
@@ -1746,10 +1746,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
     int qt0 = 0;
     if (a.causal) qt0 = max(0, kblk - shift) / BQ;
     const int per_head = max(0, nqt - qt0);
-    const int niter = per_head * GH;                                   // the same count for both teams
+    // the group's (query head, query tile) items in head-major order, cut in two: team 0 takes items [0, niter), team 1
+    // [niter, total).  Even groups: each team gets G/2 whole heads.  Odd groups (Qwen2-7B: 7): team 1 starts in the middle of
+    // a head and, when `total` is odd, sits out the last step (it still meets the barrier).
+    const int total = per_head * G, niter = (total + 1) / 2;           // the same step count for both teams
+    const int item0 = team * niter;
     float rc = 0.f;
     auto issue = [&](int it) {
-      const int g = team * GH + it / per_head, qb = (qt0 + it % per_head) * BQ;
+      const int idx = item0 + it;
+      if (idx >= total) return;
+      const int g = idx / per_head, qb = (qt0 + idx % per_head) * BQ;
       const int hq = hkv * G + g;
       const SRsrc rq = rows_rsrc((const bf16*)a.q + b * a.q_sb + hq * a.q_sh, a.Sq, a.q_ss);
       const SRsrc rdo = rows_rsrc((const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128, a.Sq, do_ss);
@@ -1772,13 +1778,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
       if (tt < 64) rowc[tt] = rc;
     }
     for (int it = 0; it < niter; ++it) {
-      const int qb = (qt0 + it % per_head) * BQ;
+      const int qb = (qt0 + (item0 + it) % per_head) * BQ;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (it + 1 < niter) issue(it + 1);
       const int so = (it & 1) * 2 * QT;
       const float* rcs = rowc + (it & 1) * 64;
-      if (!(a.causal && k0 > qb + BQ - 1 + shift)) {
+      if (item0 + it < total && !(a.causal && k0 > qb + BQ - 1 + shift)) {
         // fragment j of the 48: j < 32: k-step j >> 2, kind j & 3 (0: Q rows, 1: K rows, 2: dO rows, 3: V rows);
         //                       j >= 32: d block (j - 32) >> 2, 16-query step ((j - 32) >> 1) & 1, kind (j & 1) (0: dO^T, 1: Q^T)
         auto frag = [&](int j) -> bf16x8 {
@@ -2400,7 +2406,7 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<D>, grid, block, lds, s, a);
   }
   if (D == 128 && !attn_use_v1()) {
-    if (((a.Hq / a.Hkv) & 1) == 0 && g_attn_dkv_pair) {
+    if ((((a.Hq / a.Hkv) & 1) == 0 || g_attn_fwd_pf) && g_attn_dkv_pair) {      // the prefetching pair kernel splits any group size
       const int nkb = (a.Skv + 127) / 128;
       dim3 grid((nkb + 1) / 2, a.Hkv, a.B), block(512);
       if (g_attn_fwd_pf) {
