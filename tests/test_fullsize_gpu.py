@@ -5,7 +5,8 @@
 * config 2/3/4/5 shapes (Llama-3.1-8B / Qwen2-7B + ViT-L/14, S up to 4096, 4 images): no CPU oracle finishes in seconds at
   this size, so size-independent properties of the reference semantics are checked instead: determinism (bit-identical
   reruns), causality (a late token cannot change earlier logits), splice semantics (ids under a modality span are dead,
-  pixels are live), right-padding invariance on valid rows, loss at random init ~ ln(V), gradient accumulation linearity."""
+  pixels are live), right-padding invariance on valid rows, loss at random init ~ ln(V), gradient accumulation linearity, and
+  B = 4, S = 2048 trainer steps (AdamW, prefetcher) that fit a repeated batch and reproduce bit for bit."""
 import math
 
 import pytest
@@ -153,6 +154,52 @@ def test_config3_grad_accumulation_linearity_8b(big):
         assert torch.isfinite(c).all() and float(c.abs().sum()) > 0
         assert rel(c, a + b_) < 2e-2          # bf16 accumulation of two bf16 gradients
     del g1, g2, g12
+    flat.grad = None
+    for seg in flat.segments:
+        seg.param.grad = None
+        seg.param._mm_grad_view = None
+    torch.cuda.empty_cache()
+
+
+def test_config3_trainer_steps_8b_b4_s2048(big):
+    """The DP = 1 leg of config 2/3 at its real size through the trainer: B = 4, S = 2048, FULL mode, AdamW every step, batches
+    staged by the prefetcher (what bench.py times).  No oracle finishes at this size, so properties: the loss of a repeated batch
+    falls, the global gradient norm is finite and clipped updates move the weights, and -- since every kernel on the bf16 path
+    is deterministic (sorted embedding gradient, atomics-free attention backward) -- a second trainer started from the same
+    weights reproduces the loss sequence and the final weights BIT FOR BIT."""
+    import bench
+    from multimeditron_amd.train.prefetch import DevicePrefetcher
+    from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
+    m, llm = big
+    V = llm["vocab_size"] + 2
+    host, _ = bench.synthetic_batch(4, 2048, 1, 256, V, (V - 2, V - 1, 128002), 21, "cpu", 224, collator_form=True)
+    flat = m.flat_params()
+    w0 = flat.data.clone()
+    runs = []
+    for _ in range(2):
+        flat.data.copy_(w0)
+        tr = MultimodalTrainer(m, training_mode=TrainingMode.FULL, learning_rate=2e-5, weight_decay=0.01, max_grad_norm=1.0,
+                               max_steps=100, min_lr=2e-6)
+        feed = DevicePrefetcher(iter([host] * 3), device="cuda")
+        losses, norms = [], []
+        for b in feed:
+            losses.append(tr.training_step(b))
+            norms.append(tr.last_grad_norm)
+        tr.synchronize()
+        torch.cuda.synchronize()
+        losses = [float(x) for x in losses]
+        norms = [float(n[0]) for n in norms]
+        runs.append((losses, norms, flat.data.clone()))
+        tr.close()
+        del tr, feed
+    (l1, n1, w1), (l2, n2, w2) = runs
+    assert all(math.isfinite(x) for x in l1 + n1) and all(x > 0 for x in n1), (l1, n1)
+    assert abs(l1[0] - math.log(V)) < 1.0 and l1[2] < l1[0], l1           # random init ~ ln V; a repeated batch is being fitted
+    assert not torch.equal(w1, w0)
+    assert l1 == l2 and n1 == n2, (l1, l2, n1, n2)
+    assert torch.equal(w1, w2)
+    flat.data.copy_(w0)
+    del w0, w1, w2, runs
     flat.grad = None
     for seg in flat.segments:
         seg.param.grad = None
