@@ -87,6 +87,11 @@ int mm_gemm_sumsq(int dtype, int layout, int M, int N, int K, const void* A, int
 /* column sums: out[N] (+)= sum_m X[m,n]   (bias gradients)                                           */
 int mm_colsum(int dtype, const void* X, int M, int N, int ldx, void* out, int accumulate, void* stream);
 
+/* ids outside [0, vocab): *flag (device int, sticky) = 1.  nn.Embedding raises for them (model.py:433 embeds every id of the
+ * batch before the splice); mm_embed_splice_fwd reads row 0 instead of out of bounds, so the caller checks this flag (the
+ * Python layer reads it one call later, without a stall, and raises IndexError).                                           */
+int mm_embed_check_ids(const int64_t* ids, int T, int64_t vocab, int* flag, void* stream);
+
 /* ---- embed + modality splice: model.py:433-444 ---------------------------------------------------
  * out[t,:] = proj[src[t],:] if src[t] >= 0 else emb[ids[t],:]; src is built from (batch_idx, token_range)
  * by mm_splice_build_map (last writer wins, like index_put).                                         */

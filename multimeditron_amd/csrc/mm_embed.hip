@@ -18,6 +18,14 @@ __global__ void splice_map_kernel(const int64_t* bi, const int64_t* tr, int n_mo
   if (pos >= 0 && pos < T) atomicMax(&map[pos], i);
 }
 
+// *flag = 1 when any id lies outside [0, vocab): the reference's nn.Embedding raises (device-side assert) for such a batch,
+// also for ids under a modality span (model.py:433 embeds ALL of input_ids before the splice).  The lookup kernel below maps
+// them to row 0 so that nothing is read out of bounds; this flag is how the host gets to raise (kernels.embed_check_ids).
+__global__ __launch_bounds__(256) void embed_check_ids_kernel(const int64_t* ids, int Tn, int64_t vocab, int* flag) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < Tn && (ids[t] < 0 || ids[t] >= vocab)) *flag = 1;
+}
+
 // grid-stride over rows; one wave per row
 template <typename T>
 __global__ __launch_bounds__(256) void embed_splice_fwd_kernel(const T* emb, int64_t vocab, int H, const int64_t* ids, const T* proj,
@@ -311,6 +319,14 @@ extern "C" int mm_splice_build_map(const int64_t* batch_idx, const int64_t* toke
   hipStream_t s = (hipStream_t)stream;
   if (T > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3((T + 255) / 256), dim3(256), 0, s, src_map, T, -1);
   if (n_mod > 0) hipLaunchKernelGGL(splice_map_kernel, dim3((n_mod + 255) / 256), dim3(256), 0, s, batch_idx, token_range, n_mod, S, T, src_map);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_embed_check_ids(const int64_t* ids, int T, int64_t vocab, int* flag, void* stream) {
+  if (!ids || !flag || T < 0 || vocab <= 0) return MM_ERR_ARG;
+  if (T == 0) return MM_OK;
+  hipLaunchKernelGGL(embed_check_ids_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, T, vocab, flag);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

@@ -143,7 +143,50 @@ def splice_build_map(batch_idx, token_range, S, T):
     return m
 
 
+_oor_state = {}          # device index -> [device flag, pinned host copy, event of the last copy]
+
+
+def embed_check_ids(ids, vocab, block=False):
+    """nn.Embedding's range check without a stall: a tiny kernel raises a sticky device flag for ids outside [0, vocab); the
+    flag travels to pinned memory behind it, and the host looks at the copy of the PREVIOUS call (complete by then), or waits for
+    this one with block=True.  Raises IndexError like torch (reference model.py:433: every id of the batch is embedded)."""
+    dev = ids.device.index or 0
+    st = _oor_state.get(dev)
+    if st is None:
+        st = _oor_state[dev] = [torch.zeros(1, dtype=torch.int32, device=ids.device), torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+    _embed_raise_if_flagged(st, wait=False)
+    call("mm_embed_check_ids", _p(ids), ids.numel(), int(vocab), _p(st[0]), _stream())
+    st[1].copy_(st[0], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st[2] = ev
+    if block:
+        _embed_raise_if_flagged(st, wait=True)
+
+
+def embed_check_pending():
+    """Wait for the outstanding id checks of every device and raise if one failed (called where the host synchronises anyway)."""
+    for st in _oor_state.values():
+        _embed_raise_if_flagged(st, wait=True)
+
+
+def _embed_raise_if_flagged(st, wait):
+    ev = st[2]
+    if ev is None:
+        return
+    if wait:
+        ev.synchronize()
+    elif not ev.query():
+        return
+    st[2] = None
+    if int(st[1][0]) != 0:
+        st[0].zero_()
+        st[1].zero_()
+        raise IndexError("index out of range in self")
+
+
 def embed_splice_fwd(emb, ids, proj, src_map):
+    embed_check_ids(ids, emb.shape[0])
     T = ids.numel()
     H = emb.shape[1]
     out = torch.empty((T, H), dtype=emb.dtype, device=emb.device)

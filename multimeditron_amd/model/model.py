@@ -475,6 +475,7 @@ class MultiModalModelForCausalLM(nn.Module):
                     break
                 nxt = emb(next_ids.view(B, 1))
             ids = out_ids[:, :steps].cpu()
+            K.embed_check_pending()          # the host has just synchronised: an out-of-range input id raises here (IndexError)
         # the reference stops right after the first step at which every row has emitted eos
         done = (ids == eos).to(torch.int8).cummax(dim=1).values.bool().all(dim=0)
         if bool(done.any()):

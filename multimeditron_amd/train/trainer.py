@@ -502,6 +502,8 @@ class MultimodalTrainer:
     def synchronize(self):
         """Make the compute stream wait for the in-flight optimiser update (call before reading parameters)."""
         self._wait_optimizer()
+        if torch.cuda.is_available():
+            K.embed_check_pending()          # and surface an out-of-range token id of the steps so far (IndexError, as torch)
 
     def close(self):
         """Detach from the model (forward hooks, deferred-wgrad registration, gradient-norm slots) and release the optimiser

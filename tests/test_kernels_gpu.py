@@ -694,3 +694,29 @@ def test_fused_swiglu_gemm_bit_identical_to_two_launch_form(K, M, I, Kd):
     dgu_f = K.gemm_swiglu_bwd(dy, wd, gu, I)
     dgu = K.swiglu_bwd(gu, K.linear_dgrad(dy, wd), I)
     assert dgu_f is not None and torch.equal(dgu_f, dgu)
+
+
+def test_embedding_out_of_range_id_raises(K):      # noqa: F811
+    """nn.Embedding raises for an id outside the table (the reference embeds every id of the batch, model.py:433).  Here the
+    lookup never reads out of bounds and the error surfaces without a stall: at the next lookup after the check has completed,
+    or at the next host synchronisation point (trainer.synchronize / the end of generate)."""
+    emb = torch.randn(50, 64, device="cuda").to(torch.bfloat16)
+    good = torch.randint(0, 50, (40,), device="cuda")
+    bad = good.clone()
+    bad[7] = 50
+    K.embed_check_pending()
+    out = K.embed_splice_fwd(emb, good, None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, emb[good])
+    K.embed_splice_fwd(emb, bad, None, None)             # asynchronous: nothing raised yet
+    with pytest.raises(IndexError):
+        K.embed_check_pending()
+    K.embed_splice_fwd(emb, bad, None, None)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        K.embed_splice_fwd(emb, good, None, None)        # the next lookup finds the completed check of the previous one
+    K.embed_check_pending()                              # flag was cleared by the raise
+    neg = good.clone()
+    neg[0] = -1
+    with pytest.raises(IndexError):
+        K.embed_check_ids(neg, 50, block=True)
