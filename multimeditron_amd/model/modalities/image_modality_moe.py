@@ -1,5 +1,5 @@
-"""`moe_meditron_clip`: mixture-of-experts image modality (reference model/modalities/image_modality_moe.py:10-246 and
-model/attention.py:5-101) on libmmhip kernels.
+"""`moe_meditron_clip` and `moe_meditron_clip_pep`: the mixture-of-experts image modalities (reference
+model/modalities/image_modality_moe.py:10-246, image_modality_moe_pep.py:11-288 and model/attention.py:5-101) on libmmhip kernels.
 
 E CLIP vision towers ("experts") run on every image; a gating network scores the image; one of three fusions combines the
 experts' patch tokens; the MLP projector maps them into the LLM's embedding space:
@@ -12,6 +12,10 @@ experts' patch tokens; the MLP projector maps them into the LLM's embedding spac
 What runs where: the towers are this package's `VisionTransformer` (model/vision.py), the fusion is `mm_expert_fuse`, the
 cross-attention is three biased GEMMs + the non-causal flash-attention kernel (Nq = P queries over (E-1)*P keys) + a GEMM.
 Parameter names equal the reference's (`experts.{e}.*`, `cross_attn.{q,k,v}_proj / proj`, `projector.projection.{0,2,4}`).
+
+`moe_meditron_clip_pep` (per-expert projection) gives every expert its own MLP projector (`projectors.{e}.projection.{0,2,4}`)
+and fuses in the LLM's embedding space; its cross-attention therefore has `hidden_size / cross_attn_heads`-wide heads, which the
+bf16 attention kernels tile only for 64 and 128 (a ValueError otherwise: no silent fallback).
 
 NOT built: the reference's `GatingNetwork` is a torchvision ResNet-50 (moe/gating.py:37-89); torchvision is
 absent and a ResNet is outside the hot path.  `gating_network` is therefore a plug: any callable with the reference's output
@@ -204,4 +208,121 @@ class MOEImageModality(BaseModality):
 
     def unfreeze_projection(self):
         for p in self.projector.parameters():
+            p.requires_grad = True
+
+
+class MOEImageConfigPEP(MOEImageConfig):
+    """reference image_modality_moe_pep.py:11-52 (same arguments; its defaults)."""
+
+    def __init__(self, hidden_size: int = 4096, use_bias_proj: bool = True, expert_clip_names: Optional[List[str]] = None,
+                 image_processor: str = "openai/clip-vit-base-patch32", gating_path: str = "", top_k_experts: int = 5,
+                 projection_type: str = "mlp", generalist_idx: int = -1, fusion_method: str = "weighted_average",
+                 cross_attn_heads: int = 8, **kwargs):
+        super().__init__(hidden_size=hidden_size, use_bias_proj=use_bias_proj, expert_clip_names=expert_clip_names,
+                         image_processor=image_processor, gating_path=gating_path, top_k_experts=top_k_experts,
+                         projection_type=projection_type, generalist_idx=generalist_idx, fusion_method=fusion_method,
+                         cross_attn_heads=cross_attn_heads, **kwargs)
+
+
+class MOEImageProcessorPEP(MOEImageProcessor):
+    """reference image_modality_moe_pep.py:55-88 (identical to the shared-projector processor)."""
+
+
+@AutoModality.register("moe_meditron_clip_pep")
+class MOEImageModalityPEP(BaseModality):
+    """reference image_modality_moe_pep.py:91-288: experts -> one projector PER expert -> fusion in the projected space."""
+    config_class = MOEImageConfigPEP
+    preprocessor_class = MOEImageProcessorPEP
+
+    def __init__(self, config: MOEImageConfigPEP, dtype: torch.dtype = torch.bfloat16, device=None,
+                 gating_network: Optional[Callable] = None):
+        super().__init__(config, dtype=dtype)
+        self.expert_names: List[str] = list(config.expert_clip_names)
+        assert len(self.expert_names) > 0, "No experts provided in config.expert_clip_names."
+        self.experts = nn.ModuleList()
+        self.projectors = nn.ModuleList()
+        vis0 = None
+        for name in self.expert_names:
+            vis = VisionConfig.from_dict(resolve_vision_config(name))
+            if vis0 is None:
+                vis0 = vis
+            elif (vis.image_size, vis.patch_size) != (vis0.image_size, vis0.patch_size):      # reference :131-137
+                raise ValueError("sequence_append requires identical (image_size, patch_size) across experts.")
+            self.experts.append(VisionTransformer(vis, dtype, device))
+            if config.projection_type != "mlp":
+                raise ValueError(f"Unsupported projection_type: {config.projection_type}")
+            self.projectors.append(MLPProjector(vis.hidden_size, config.hidden_size, dtype=dtype, device=device))
+        self.embedding_size = config.hidden_size                         # post-projection width seen by the LLM (:252-254)
+        self._num_patches_per_entry = vis0.num_patches
+        self.generalist_idx = config.generalist_idx
+        self.fusion_method = config.fusion_method.replace("-", "_")
+        self.gating_network = gating_network
+        names = list(getattr(getattr(gating_network, "config", None), "class_names", []) or [])
+        if names:
+            lookup = {nm: i for i, nm in enumerate(self.expert_names)}
+            try:
+                perm = [lookup[nm] for nm in names]
+            except KeyError as e:
+                raise ValueError(f"Gating class name {e} not found in expert_clip_names: {self.expert_names}")
+        else:
+            perm = list(range(len(self.experts)))
+        self.register_buffer("_gating_to_expert_perm", torch.tensor(perm, dtype=torch.long), persistent=False)
+        if self.fusion_method == "cross_attn":
+            self.cross_attn = CrossAttention(config.hidden_size, num_heads=config.cross_attn_heads, qkv_bias=True, dtype=dtype,
+                                             device=device)
+        self.modality_frozen = not self.training
+
+    @property
+    def device(self):
+        return self.experts[0].embeddings.patch_embedding.weight.device
+
+    def forward(self, inputs, stages=None) -> torch.Tensor:
+        pixels = torch.stack(list(inputs), dim=0) if not torch.is_tensor(inputs) else inputs
+        pixels = pixels.to(self.device, non_blocking=True)
+        n, E = pixels.shape[0], len(self.experts)
+        if self.gating_network is None:
+            raise NotImplementedError(
+                "MOEImageModalityPEP needs a gating network: assign `modality.gating_network = fn` with fn(pixels [n,3,H,W]) -> "
+                "(logits, topk_indices, weights [n, E]) (reference moe/gating.py:73-89; its ResNet-50 is not part of this build).")
+        _logits, _topk, weights = self.gating_network(pixels)
+        w_raw = weights.to(device=self.device, dtype=torch.float32).contiguous()          # gate order, as weighted_average uses it (:214)
+        outs = []
+        for expert, projector in zip(self.experts, self.projectors):
+            hs = expert(pixels).last_hidden_state                         # [n, 1+P, C_e]
+            T = hs.shape[1]
+            outs.append(projector(Fm.drop_cls(hs.reshape(n * T, -1), n, T)))              # [n, P, H]
+        stacked = torch.stack(outs, dim=0)                                # [E, n, P, H]
+        P, H = stacked.shape[2], stacked.shape[3]
+        if self.fusion_method == "sequence_append":
+            fused = stacked.permute(1, 0, 2, 3).reshape(n, E * P, H)
+        elif self.fusion_method == "weighted_average":
+            fused = Fm.expert_fuse(stacked, w_raw, list(range(E)), 0)
+        elif self.fusion_method == "cross_attn":
+            gi = self.generalist_idx % E
+            spec = [i for i in range(E) if i != gi]
+            w_exp = w_raw.index_select(-1, self._gating_to_expert_perm.to(w_raw.device)).contiguous()     # expert order (:229-230)
+            ctx = Fm.expert_fuse(stacked, w_exp, spec, 1)
+            fused = self.cross_attn(stacked[gi], ctx)
+        else:
+            raise ValueError(f"Unsupported fusion_method: {self.fusion_method}")
+        fused = fused.contiguous()
+        if stages is not None:
+            stages["moe_fused"] = fused
+            stages["projector_out"] = fused
+        return fused
+
+    def freeze_modality_embedder(self):
+        for e in self.experts:
+            for p in e.parameters():
+                p.requires_grad = False
+        self.modality_frozen = True
+
+    def unfreeze_modality_embedder(self):
+        for e in self.experts:
+            for p in e.parameters():
+                p.requires_grad = True
+        self.modality_frozen = False
+
+    def unfreeze_projection(self):
+        for p in self.projectors.parameters():
             p.requires_grad = True

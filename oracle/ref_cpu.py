@@ -185,6 +185,28 @@ def moe_image_modality(w, pixels, gate_weights, vis, num_experts, fusion, genera
     return mlp_projector(w, fused, prefix="projector.projection.")
 
 
+def moe_image_modality_pep(w, pixels, gate_weights, vis, num_experts, fusion, generalist_idx=-1, heads=8, perm=None):
+    """image_modality_moe_pep.py:191-249 (per-expert projection): every expert tower on every image (CLS dropped), each
+    through ITS OWN MLP projector (`projectors.{e}.projection.*`), then the fusion in the projected space.  As in the
+    reference, `weighted_average` takes the gate's weights as they come (:214-216) and only `cross_attn` aligns them to the
+    expert order with `perm` (:229-230)."""
+    outs = [mlp_projector(w, clip_vision_tower(w, pixels, vis, prefix=f"experts.{e}.")[:, 1:, :], prefix=f"projectors.{e}.projection.")
+            for e in range(num_experts)]
+    st = torch.stack(outs, dim=1)                                     # [n, E, P, H]
+    if fusion == "sequence_append":
+        return torch.flatten(st, 1, 2)
+    if fusion == "weighted_average":
+        return (st * gate_weights.to(st.dtype)[:, :, None, None]).sum(dim=1)
+    if fusion == "cross_attn":
+        E = num_experts
+        gw = gate_weights if perm is None else gate_weights.index_select(-1, perm)
+        spec = [i for i in range(E) if i != generalist_idx]           # the reference indexes with generalist_idx as given (:220-223)
+        ws = torch.softmax(gw[:, spec], dim=-1).to(st.dtype)
+        ctx = [st[:, e] * ws[:, j].view(-1, 1, 1) for j, e in enumerate(spec)]
+        return cross_attention(w, "cross_attn.", st[:, generalist_idx], ctx, heads)
+    raise ValueError(f"Unsupported fusion_method: {fusion}")
+
+
 # ------------------------------------------------------------------------------------------
 # splice
 # ------------------------------------------------------------------------------------------

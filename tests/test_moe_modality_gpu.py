@@ -1,5 +1,5 @@
-"""MoE image modality on the HIP path (GPU) against vectors produced by the REAL reference classes (MOEImageModality +
-CrossAttention, eval mode; tools/make_golden.py moe_fixture): outputs of all three fusions and the gradients of the projector,
+"""MoE image modalities on the HIP path (GPU) against vectors produced by the REAL reference classes (MOEImageModality,
+MOEImageModalityPEP + CrossAttention, eval mode; tools/make_golden.py moe_fixture): outputs of all three fusions and the gradients of the projector,
 the cross-attention, and expert layers.  The gate is a stub with the reference gate's output contract (the ResNet-50 gate is
 not part of this build: parity-unpinned).  fp32 path <= 1e-4 (outputs) / 1e-3 (grads); bf16 path <= 3e-2 / 6e-2."""
 import json
@@ -27,8 +27,20 @@ def moe(golden_dir):
     return meta, w, v
 
 
+@pytest.fixture(scope="module")
+def moe_pep(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    meta = json.load(open(os.path.join(golden_dir, "tiny_moe_clip_pep.meta.json")))
+    w = load_file(os.path.join(golden_dir, "tiny_moe_clip_pep.weights.safetensors"))
+    v = load_file(os.path.join(golden_dir, "tiny_moe_clip_pep.vectors.safetensors"))
+    return meta, w, v
+
+
 def _build(meta, w, v, fusion, dtype, tmp):
     from multimeditron_amd.model.modalities import MOEImageConfig, MOEImageModality
+    if meta.get("per_expert_projection"):
+        from multimeditron_amd.model.modalities import MOEImageConfigPEP as MOEImageConfig, MOEImageModalityPEP as MOEImageModality
     from multimeditron_amd.nn import FlatParams
     E = meta["num_experts"]
     dirs = []
@@ -52,7 +64,7 @@ def _build(meta, w, v, fusion, dtype, tmp):
         for k, p in own.items():
             p.copy_(w[k].to(dtype).reshape(p.shape))
     assert set(own) <= set(w)
-    FlatParams([(k, p, "projector" if k.startswith("projector.") else "encoder") for k, p in own.items()], "cuda", dtype)
+    FlatParams([(k, p, "projector" if k.startswith("projector") else "encoder") for k, p in own.items()], "cuda", dtype)
     for p in m.parameters():
         p.requires_grad_(True)
     return m
@@ -88,3 +100,29 @@ def test_moe_gate_is_a_plug(moe, tmp_path):
     m.gating_network = None
     with pytest.raises(NotImplementedError):
         m([v["pixels"][0]])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fusion", ["weighted_average", "sequence_append", "cross_attn"])
+def test_moe_pep_fusions_match_reference(moe_pep, tmp_path, fusion, dtype):
+    """MOEImageModalityPEP (reference image_modality_moe_pep.py): one projector per expert, fusion in the projected space."""
+    meta, w, v = moe_pep
+    m = _build(meta, w, v, fusion, dtype, tmp_path)
+    assert type(m).__name__ == "MOEImageModalityPEP" and len(m.projectors) == meta["num_experts"]
+    px = v["pixels"]
+    y = m([px[i] for i in range(px.shape[0])])
+    tol_o, tol_g = (1e-4, 1e-3) if dtype == torch.float32 else (3e-2, 6e-2)
+    assert y.shape == v[f"{fusion}.out"].shape
+    assert rel(y.float(), v[f"{fusion}.out"]) < tol_o
+    y.backward(v[f"{fusion}.dout"].to(dtype).cuda())
+    torch.cuda.synchronize()
+    own = dict(m.named_parameters())
+    n = 0
+    for key, ref in v.items():
+        if not key.startswith(f"{fusion}.grad.") or ref.dim() < 2:
+            continue
+        g = own[key[len(fusion) + 6:]].grad
+        assert g is not None, key
+        assert rel(g.float().reshape(ref.shape), ref) < tol_g, key
+        n += 1
+    assert n >= 10

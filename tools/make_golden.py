@@ -448,8 +448,15 @@ def siglip_fixture(name="tiny_siglip_qwen2", seed=300):
 # torchvision ResNet-50 (absent here: its arithmetic stays "parity unpinned"); the harness plugs a stub with the gate's
 # OUTPUT CONTRACT (logits, top-k indices, softmax weights) so that everything downstream of the gate is pinned:
 #     weights = softmax(mean_hw(pixels) @ Wg^T + bg)
-def moe_fixture(name="tiny_moe_clip", seed=500):
-    import multimeditron.model.modalities.image_modality_moe as moe
+def moe_fixture(name="tiny_moe_clip", seed=500, pep=False):
+    """pep=False: the reference's MOEImageModality (one projector after the fusion); pep=True: MOEImageModalityPEP
+    (image_modality_moe_pep.py: one projector PER EXPERT, fusion and cross-attention in the projected space)."""
+    if pep:
+        import multimeditron.model.modalities.image_modality_moe_pep as moe
+        moe.MOEImageConfig, moe.MOEImageModality = moe.MOEImageConfigPEP, moe.MOEImageModalityPEP
+        moe.AutoModel = types.SimpleNamespace(from_pretrained=lambda path, trust_remote_code=True: transformers.CLIPModel.from_pretrained(path))
+    else:
+        import multimeditron.model.modalities.image_modality_moe as moe
     moe.AutoImageProcessor = types.SimpleNamespace(from_pretrained=CLIPImageProcessorPil.from_pretrained)
     E = 3
 
@@ -507,7 +514,7 @@ def moe_fixture(name="tiny_moe_clip", seed=500):
             for nme, q in m.named_parameters():
                 if q.grad is not None and not nme.startswith("gating_network.") and (
                         "projector" in nme or "cross_attn" in nme or "experts.0.encoder.layers.1" in nme or "experts.2.embeddings" in nme
-                        or "experts.1.encoder.layers.0.mlp" in nme):
+                        or "experts.1.encoder.layers.0.mlp" in nme):     # "projector" also matches PEP's projectors.{e}.*
                     out[f"{fusion}.grad.{nme}"] = q.grad.detach().float().clone()
             with torch.no_grad():
                 _, _, gw = m.gating_network(torch.stack(pixels))
@@ -527,7 +534,7 @@ def moe_fixture(name="tiny_moe_clip", seed=500):
     save_file(weights, os.path.join(OUT, f"{name}.weights.safetensors"))
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(OUT, f"{name}.vectors.safetensors"))
     with open(os.path.join(OUT, f"{name}.meta.json"), "w") as f:
-        json.dump(dict(name=name, vision=VIS, num_experts=E, generalist_idx=E - 1, cross_attn_heads=2, hidden_size=128,
+        json.dump(dict(name=name, vision=VIS, num_experts=E, generalist_idx=E - 1, cross_attn_heads=2, hidden_size=128, per_expert_projection=bool(pep),
                        fusions=["weighted_average", "sequence_append", "cross_attn"], transformers=transformers.__version__,
                        torch=torch.__version__,
                        note="reference MOEImageModality in eval mode (dropout off) with a stub gate standing for the torchvision "
@@ -669,7 +676,7 @@ def collator_fixture():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["llama", "qwen2", "llama_d128", "siglip", "moe", "collator"]
+    which = sys.argv[1:] or ["llama", "qwen2", "llama_d128", "siglip", "moe", "moe_pep", "collator"]
     if "llama" in which:
         model_fixture("tiny_clip_llama", llama_cfg(), 100)
     if "qwen2" in which:
@@ -680,5 +687,7 @@ if __name__ == "__main__":
         siglip_fixture()
     if "moe" in which:
         moe_fixture()
+    if "moe_pep" in which:
+        moe_fixture("tiny_moe_clip_pep", 600, pep=True)
     if "collator" in which:
         collator_fixture()
