@@ -19,8 +19,8 @@ bf16 attention kernels tile only for 64 and 128 (a ValueError otherwise: no sile
 
 NOT built: the reference's `GatingNetwork` is a torchvision ResNet-50 (moe/gating.py:37-89); torchvision is
 absent and a ResNet is outside the hot path.  `gating_network` is therefore a plug: any callable with the reference's output
-contract `pixels [n,3,H,W] -> (logits [n,E], topk_indices, weights [n,E])`.  The experts run one after the other (E x the
-single-tower launches); batching them as one grouped GEMM is the next step.  `CrossAttention`'s dropout (p = 0.1, active in the
+contract `pixels [n,3,H,W] -> (logits [n,E], topk_indices, weights [n,E])`.  The experts run side by side, each on its own HIP
+stream (`_run_experts`); a grouped multi-expert GEMM launch would be the step after that.  `CrossAttention`'s dropout (p = 0.1, active in the
 reference whenever the module is in train mode) is not implemented: outputs equal the reference in eval mode."""
 from __future__ import annotations
 
@@ -111,6 +111,47 @@ class CrossAttention(nn.Module):
         return self.proj(o).view(n, Nq, C)
 
 
+def _run_experts(experts, pixels, post=None):
+    """Every expert tower on the same pixels, each on ITS OWN HIP stream: at the modality's size (ViT on a few hundred rows) the
+    towers are launch-latency-bound chains of short kernels, so E of them side by side take little more than one (the "batched
+    multi-expert ViT" of SURVEY 8f-4, done with streams instead of a grouped launch: same kernels, same results bit for bit).
+    Autograd replays each tower's backward on the stream its forward ran on.  `post(e, tokens)` is applied on the expert's stream
+    (the per-expert projector of the PEP variant).  MM_MOE_STREAMS=0: one after the other on the current stream."""
+    import os
+    n = pixels.shape[0]
+
+    def tower(e, expert):
+        hs = expert(pixels).last_hidden_state                             # [n, 1+P, C]
+        T = hs.shape[1]
+        out = Fm.drop_cls(hs.reshape(n * T, -1), n, T)                    # [n, P, C]
+        return post(e, out) if post is not None else out
+
+    if len(experts) == 1 or not pixels.is_cuda or os.environ.get("MM_MOE_STREAMS", "1") == "0":
+        return [tower(e, ex) for e, ex in enumerate(experts)]
+    main = torch.cuda.current_stream()
+    outs = []
+    for e, ex in enumerate(experts):
+        st = _expert_stream(pixels.device, e)
+        st.wait_stream(main)                                              # pixels (and the previous step's work) are ready
+        with torch.cuda.stream(st):
+            o = tower(e, ex)
+        o.record_stream(main)                                             # produced on `st`, consumed on the compute stream
+        outs.append((o, st))
+    for _, st in outs:
+        main.wait_stream(st)
+    return [o for o, _ in outs]
+
+
+_EXPERT_STREAMS = {}
+
+
+def _expert_stream(device, e):
+    key = (device.index or 0, e)
+    if key not in _EXPERT_STREAMS:
+        _EXPERT_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _EXPERT_STREAMS[key]
+
+
 @AutoModality.register("moe_meditron_clip")
 class MOEImageModality(BaseModality):
     config_class = MOEImageConfig
@@ -170,11 +211,7 @@ class MOEImageModality(BaseModality):
         pixels = pixels.to(self.device, non_blocking=True)
         n, E = pixels.shape[0], len(self.experts)
         w = self.gate_weights(pixels)                                     # [n, E] fp32, expert order
-        feats = []
-        for expert in self.experts:                                       # every expert on every image (reference :156-160)
-            hs = expert(pixels).last_hidden_state                         # [n, 1+P, C]
-            T = hs.shape[1]
-            feats.append(Fm.drop_cls(hs.reshape(n * T, -1), n, T))        # [n, P, C]
+        feats = _run_experts(self.experts, pixels)                        # every expert on every image (reference :156-160)
         stacked = torch.stack(feats, dim=0)                               # [E, n, P, C] (device copy; autograd unbinds it)
         P, C = stacked.shape[2], stacked.shape[3]
         if self.fusion_method == "sequence_append":
@@ -286,11 +323,7 @@ class MOEImageModalityPEP(BaseModality):
                 "(logits, topk_indices, weights [n, E]) (reference moe/gating.py:73-89; its ResNet-50 is not part of this build).")
         _logits, _topk, weights = self.gating_network(pixels)
         w_raw = weights.to(device=self.device, dtype=torch.float32).contiguous()          # gate order, as weighted_average uses it (:214)
-        outs = []
-        for expert, projector in zip(self.experts, self.projectors):
-            hs = expert(pixels).last_hidden_state                         # [n, 1+P, C_e]
-            T = hs.shape[1]
-            outs.append(projector(Fm.drop_cls(hs.reshape(n * T, -1), n, T)))              # [n, P, H]
+        outs = _run_experts(self.experts, pixels, post=lambda e, tok: self.projectors[e](tok))      # [n, P, H] each
         stacked = torch.stack(outs, dim=0)                                # [E, n, P, H]
         P, H = stacked.shape[2], stacked.shape[3]
         if self.fusion_method == "sequence_append":
