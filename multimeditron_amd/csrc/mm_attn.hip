@@ -1688,6 +1688,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pair_kernel(AttnArgs a
 //   * K is an LDS image like V instead of 32 registers of fragments: that pays for a 4-deep fragment ring over the 48
 //     fragments of an iteration (Q, K, dO, V row fragments for S^T and dP^T; dO^T, Q^T transposed fragments for dV, dK);
 //   * the row constants are read as eight 16-byte vectors (rows 8g + 4h .. + 3 are consecutive), issued together.
+template <int RD>                      // fragment ring slots: 8 (6 fragments in flight) or 4 (the round-2 first cut, kept for A/B)
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs a) {
   constexpr int BQ = 32, NDB = 4, QT = BQ * 256, IMG = 128 * 256;     // 8 KiB per 32-row tile, 32 KiB per 128-key image
   extern __shared__ __attribute__((aligned(16))) char smem[];          // [V image | K image | 2 teams x 2 stages x (Q | dO) | row constants]
@@ -1804,7 +1805,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
           o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
           return o;
         };
-        constexpr int RD = 4;
+        // S^T and dP^T take TWO fresh fragments per MFMA (K and Q rows, V and dO rows), so a 4-slot ring gave each product one
+        // MFMA (32 cycles) of lookahead against an LDS round trip of 100+ cycles: rocprofv3 showed the waves parked 55 % of
+        // their cycles with the LDS 30 % busy and no bank conflicts -- latency, not bandwidth.  8 slots, 6 fragments in flight
+        // (3 MFMAs ahead); the 32 registers this costs are the row constants', which are now read AFTER the products.
+        constexpr int LA = RD == 8 ? 6 : 4;
+        f32x16 s_acc, dp_acc;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bf16x8 fr[RD];                                                 // ring: fragment j lives in fr[j % RD]
+#pragma unroll
+        for (int j = 0; j < LA; ++j) fr[j] = frag(j);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {                                 // MFMA m uses fragments 2m (A) and 2m + 1 (B); once it is
+          if (m & 1) dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], m > 1 ? dp_acc : zero16, 0, 0, 0);   // issued
+          else s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], m > 1 ? s_acc : zero16, 0, 0, 0);          // the slots
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {                                // of MFMA m - 1 take the fragments of MFMA m + 3; the last
+            const int jn = 2 * m + LA + t;                             // steps fetch the first four transposed fragments (32 .. 35)
+            if (jn < 36) fr[jn % RD] = frag(jn);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
         // row constants of the lane's 16 query rows: rows 8g + 4h + (0..3), g = 0..3 -> 4 + 4 vectors of 16 bytes
         f32x4 lsev[4], dltv[4];
 #pragma unroll
@@ -1812,22 +1835,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
           lsev[g4] = *(const f32x4*)(rcs + 8 * g4 + 4 * h);
           dltv[g4] = *(const f32x4*)(rcs + 32 + 8 * g4 + 4 * h);
         }
-        f32x16 s_acc, dp_acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; dp_acc[r] = 0.f; }
-        bf16x8 fr[RD];                                                 // ring: fragment j lives in fr[j % RD]
-#pragma unroll
-        for (int j = 0; j < RD; ++j) fr[j] = frag(j);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {                                 // MFMA m uses fragments 2m (A) and 2m + 1 (B); once it is
-          if (m & 1) dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], dp_acc, 0, 0, 0);   // issued
-          else s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], s_acc, 0, 0, 0);          // their slots
-          fr[(2 * m) % RD] = frag(2 * m + RD);                         // take the fragments of MFMA m + 2 (the last two chunks
-          fr[(2 * m + 1) % RD] = frag(2 * m + 1 + RD);                 // already fetch transposed fragments 32 .. 35)
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_setprio(0);
         bf16x8 pf[2], dsf[2];
         const bool need_mask = (__ballot(kvalid) != ~0ull) || (a.causal && (k0 + 31) > (qb + shift));
 #pragma unroll
@@ -1850,7 +1857,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
           const int db = m >> 2, s16 = (m >> 1) & 1;
           if (m & 1) dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(32 + m) % RD], dsf[s16], dk_acc[db], 0, 0, 0);
           else dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(32 + m) % RD], pf[s16], dv_acc[db], 0, 0, 0);
-          if (32 + m + RD < 48) fr[(32 + m) % RD] = frag(32 + m + RD);
+          if (32 + m + 4 < 48) fr[(32 + m + 4) % RD] = frag(32 + m + 4);
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
@@ -2321,6 +2328,7 @@ __global__ void attn_decode_merge_kernel(const float* ws, int nsplit, bf16* out)
 int g_attn_fwd_waves = 8;     // waves per workgroup of the D=128 forward (mm_set_option "attn_fwd_waves": 8 or 4)
 int g_attn_fwd_pf = 1;        // D=128 forward with prefetched fragments (attn_fwd128p_kernel; mm_set_option "attn_fwd_pf" 0 = the older kernel)
 int g_attn_fwd_q = 1;         // D=128 forward with the two waves of a SIMD out of phase (attn_fwd128q_kernel; "attn_fwd_q" 0 = attn_fwd128p_kernel)
+int g_attn_dkv_rd = 8;        // fragment ring slots of attn_bwd_dkv128_pairp_kernel ("attn_dkv_rd": 8 or 4)
 int g_attn_q_rd = 4;          // fragment ring depth of attn_fwd128q_kernel ("attn_q_rd": 4, 6 or 8)
 int g_attn_diag = 0;          // AttnArgs::diag ("attn_diag")
 int g_attn_q_prio = 1;        // s_setprio policy of the out-of-phase kernels (AttnArgs::prio; "attn_q_prio")
@@ -2411,8 +2419,13 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
       dim3 grid((nkb + 1) / 2, a.Hkv, a.B), block(512);
       if (g_attn_fwd_pf) {
         const size_t lds = 2 * 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);      // V + K images, rings, row constants
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pairp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(attn_bwd_dkv128_pairp_kernel, grid, block, lds, s, a);
+        if (g_attn_dkv_rd == 4) {
+          (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pairp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL(attn_bwd_dkv128_pairp_kernel<4>, grid, block, lds, s, a);
+        } else {
+          (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pairp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL(attn_bwd_dkv128_pairp_kernel<8>, grid, block, lds, s, a);
+        }
       } else {
         const size_t lds = 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2439,6 +2452,7 @@ int mm_attn_option(const char* name, int value) {   // reached through mm_set_op
   if (!strcmp(name, "attn_fwd_pf")) { g_attn_fwd_pf = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_fwd_q")) { g_attn_fwd_q = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_q_prio")) { g_attn_q_prio = value; return MM_OK; }
+  if (!strcmp(name, "attn_dkv_rd")) { g_attn_dkv_rd = value == 4 ? 4 : 8; return MM_OK; }
   if (!strcmp(name, "attn_q_rd")) { g_attn_q_rd = value; return MM_OK; }
   if (!strcmp(name, "attn_diag")) { g_attn_diag = value; return MM_OK; }
   if (!strcmp(name, "attn_fwd_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_attn_fwd_waves = value; return MM_OK; }

@@ -101,6 +101,15 @@ if "--ab-q" in sys.argv:         # D=128 forward: waves of a SIMD in phase (p ke
     run(4, 2048, 28, 4, 128, True)
     run(4, 2048, 32, 8, 128, True, mask=True)
     sys.exit(0)
+if "--ab-dkv" in sys.argv:       # dK/dV fragment ring: 4 slots vs 8 (same process, interleaved)
+    run(4, 2048, 32, 8, 128, True)
+    for rd in (4, 8, 4, 8, 4, 8):
+        lib().mm_set_option(b"attn_dkv_rd", rd)
+        print("attn_dkv_rd", rd)
+        run(4, 2048, 32, 8, 128, True)
+    run(2, 4096, 32, 8, 128, True)
+    run(4, 2048, 28, 4, 128, True)
+    sys.exit(0)
 if "--diag-q" in sys.argv:       # timing experiments on the out-of-phase forward (wrong results by design)
     lib().mm_set_option(b"attn_q_prio", 1)
     run(4, 2048, 32, 8, 128, True)
