@@ -1697,7 +1697,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
   const int team = w >> 2, wt = w & 3, tt = threadIdx.x & 255;
   float* red = (float*)(smem + 2 * IMG);                               // 64 KiB = both rings, reused for the team sum
   float* rowc = (float*)(smem + 2 * IMG + 8 * QT) + team * 128;        // per team [2 stages][lse*log2e (32) | delta (32)]
-  const int b = blockIdx.z, hkv = blockIdx.y;
+  // 1-D grid, XCD-aware: the hardware deals consecutive workgroup ids to the 8 XCDs in turn, and the `npair` workgroups of one
+  // (batch, KV head) stream the SAME Q / dO rows (G heads x Sq x 512 B).  With a (pair, head, batch) grid those workgroups sat
+  // on 8 different XCDs, every L2 saw each tile once and the kernel pulled 4.5x its algorithmic bytes from beyond L2.  Here
+  // group g = (b, hkv) lives on XCD g % 8 and its pairs fill that XCD's consecutive slots (needs B * Hkv % 8 == 0, else the
+  // plain order).
+  const int npair = (((a.Skv + 127) / 128) + 1) / 2, ngroup = a.B * a.Hkv;
+  int pair_i, grp;
+  if ((ngroup & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    pair_i = slot % npair;
+    grp = (slot / npair) * 8 + xcd;
+  } else {
+    pair_i = blockIdx.x % npair;
+    grp = blockIdx.x / npair;
+  }
+  const int b = grp / a.Hkv, hkv = grp % a.Hkv;
   const int G = a.Hq / a.Hkv;
   const int nkb = (a.Skv + 127) / 128;
   const int shift = a.Skv - a.Sq;
@@ -1721,8 +1736,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
   }
 
   for (int pass = 0; pass < 2; ++pass) {
-    const int kb = pass == 0 ? (int)blockIdx.x : nkb - 1 - (int)blockIdx.x;
-    if (pass == 1 && kb <= (int)blockIdx.x) break;                    // odd count: the middle block has no partner
+    const int kb = pass == 0 ? pair_i : nkb - 1 - pair_i;
+    if (pass == 1 && kb <= pair_i) break;                    // odd count: the middle block has no partner
     const int kblk = kb * 128;
     const int k0 = kblk + wt * 32;
     const int ki = k0 + (l & 31);
@@ -2418,6 +2433,9 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
       const int nkb = (a.Skv + 127) / 128;
       dim3 grid((nkb + 1) / 2, a.Hkv, a.B), block(512);
       if (g_attn_fwd_pf) {
+        const int64_t nwg = (int64_t)((nkb + 1) / 2) * a.Hkv * a.B;       // 1-D: the kernel deals (pair, head, batch) XCD-aware
+        if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
+        grid = dim3((unsigned)nwg);
         const size_t lds = 2 * 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);      // V + K images, rings, row constants
         if (g_attn_dkv_rd == 4) {
           (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pairp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
