@@ -1688,7 +1688,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pair_kernel(AttnArgs a
 //   * K is an LDS image like V instead of 32 registers of fragments: that pays for a 4-deep fragment ring over the 48
 //     fragments of an iteration (Q, K, dO, V row fragments for S^T and dP^T; dO^T, Q^T transposed fragments for dV, dK);
 //   * the row constants are read as eight 16-byte vectors (rows 8g + 4h .. + 3 are consecutive), issued together.
-template <int RD>                      // fragment ring slots: 8 (6 fragments in flight) or 4 (the round-2 first cut, kept for A/B)
+#ifndef MM_DKV_DIAG                 // timing experiments on the paired dK/dV kernel (results wrong by design; tools/build_diag.sh):
+#define MM_DKV_DIAG 0               // 1 no Q/dO DMA, 2 no softmax/dS VALU, 4 no S/dP MFMAs, 8 no dV/dK MFMAs, 16 no LDS fragment reads, 32 no barrier
+#endif
+template <int RD, bool DKV_LATE_ISSUE> // RD fragment ring slots: 8 (6 fragments in flight) or 4; DKV_LATE_ISSUE: DMA of the next tile after the S/dP products
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs a) {
   constexpr int BQ = 32, NDB = 4, QT = BQ * 256, IMG = 128 * 256;     // 8 KiB per 32-row tile, 32 KiB per 128-key image
   extern __shared__ __attribute__((aligned(16))) char smem[];          // [V image | K image | 2 teams x 2 stages x (Q | dO) | row constants]
@@ -1770,7 +1773,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
     float rc = 0.f;
     auto issue = [&](int it) {
       const int idx = item0 + it;
-      if (idx >= total) return;
+      if (idx >= total || (MM_DKV_DIAG & 1)) return;
       const int g = idx / per_head, qb = (qt0 + idx % per_head) * BQ;
       const int hq = hkv * G + g;
       const SRsrc rq = rows_rsrc((const bf16*)a.q + b * a.q_sb + hq * a.q_sh, a.Sq, a.q_ss);
@@ -1796,14 +1799,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
     for (int it = 0; it < niter; ++it) {
       const int qb = (qt0 + (item0 + it) % per_head) * BQ;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (it + 1 < niter) issue(it + 1);
+      if (!(MM_DKV_DIAG & 32)) __builtin_amdgcn_s_barrier();
+      // The next tile's DMA (4 pieces per wave) is NOT issued here: in front of the S / dP products it shares the LDS path with
+      // their 32 fragment reads and costs 100-185 cycles per piece (timing build without the DMA: -25 % kernel time).  It is
+      // issued after those products, in front of the VALU-only dS segment (MI355X_MICROARCH.md: 25-60 cycles there).  Its ring
+      // slot was last read in iteration it - 1, which every wave of the team left before this barrier.
+      bool issued = false;
+      if (!DKV_LATE_ISSUE && it + 1 < niter) { issue(it + 1); issued = true; }
       const int so = (it & 1) * 2 * QT;
       const float* rcs = rowc + (it & 1) * 64;
       if (item0 + it < total && !(a.causal && k0 > qb + BQ - 1 + shift)) {
         // fragment j of the 48: j < 32: k-step j >> 2, kind j & 3 (0: Q rows, 1: K rows, 2: dO rows, 3: V rows);
         //                       j >= 32: d block (j - 32) >> 2, 16-query step ((j - 32) >> 1) & 1, kind (j & 1) (0: dO^T, 1: Q^T)
         auto frag = [&](int j) -> bf16x8 {
+          if (MM_DKV_DIAG & 16) { bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (bf16)(float)(j + l); return z; }
           if (j < 32) {
             const int ds = j >> 2, kind = j & 3, a2 = ds & 1, off = 512 * (ds >> 1);
             if (kind == 0) return *(const bf16x8*)(ring_r[a2] + so + off);
@@ -1833,7 +1842,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 16; ++m) {                                 // MFMA m uses fragments 2m (A) and 2m + 1 (B); once it is
-          if (m & 1) dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], m > 1 ? dp_acc : zero16, 0, 0, 0);   // issued
+          if (MM_DKV_DIAG & 4) { if (m < 2) { dp_acc = zero16; s_acc = zero16; } }
+          else if (m & 1) dp_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], m > 1 ? dp_acc : zero16, 0, 0, 0);   // issued
           else s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(2 * m) % RD], fr[(2 * m + 1) % RD], m > 1 ? s_acc : zero16, 0, 0, 0);          // the slots
 #pragma unroll
           for (int t = 0; t < 2; ++t) {                                // of MFMA m - 1 take the fragments of MFMA m + 3; the last
@@ -1843,6 +1853,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
+        if (DKV_LATE_ISSUE && it + 1 < niter) { issue(it + 1); issued = true; }
         // row constants of the lane's 16 query rows: rows 8g + 4h + (0..3), g = 0..3 -> 4 + 4 vectors of 16 bytes
         f32x4 lsev[4], dltv[4];
 #pragma unroll
@@ -1851,6 +1862,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
           dltv[g4] = *(const f32x4*)(rcs + 32 + 8 * g4 + 4 * h);
         }
         bf16x8 pf[2], dsf[2];
+        if (MM_DKV_DIAG & 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { pf[r >> 3][r & 7] = (bf16)s_acc[r]; dsf[r >> 3][r & 7] = (bf16)(dp_acc[r] + lsev[r >> 2][r & 3] + dltv[r >> 2][r & 3]); }
+        } else {
         const bool need_mask = (__ballot(kvalid) != ~0ull) || (a.causal && (k0 + 31) > (qb + shift));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1865,18 +1880,21 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv128_pairp_kernel(AttnArgs 
           pf[r >> 3][r & 7] = (bf16)p;
           dsf[r >> 3][r & 7] = (bf16)dsv;
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 16; ++m) {                                 // fragment 32 + m: d block m >> 2, query step (m >> 1) & 1
           const int db = m >> 2, s16 = (m >> 1) & 1;
-          if (m & 1) dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(32 + m) % RD], dsf[s16], dk_acc[db], 0, 0, 0);
+          if (MM_DKV_DIAG & 8) { dk_acc[db][m] += (float)fr[(32 + m) % RD][0] + (float)dsf[s16][0] + (float)pf[s16][0]; }
+          else if (m & 1) dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(32 + m) % RD], dsf[s16], dk_acc[db], 0, 0, 0);
           else dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(32 + m) % RD], pf[s16], dv_acc[db], 0, 0, 0);
           if (32 + m + 4 < 48) fr[(32 + m + 4) % RD] = frag(32 + m + 4);
           __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
       }
+      if (!issued && it + 1 < niter) issue(it + 1);                     // a wave that skipped the tile (or the early-issue build)
       if (it + 1 < niter && tt < 64) rowc[((it + 1) & 1) * 64 + tt] = rc;
     }
     // ---- sum the two teams' accumulators through LDS (team 1 writes, team 0 adds: fixed order), then team 0 stores
@@ -2343,6 +2361,7 @@ __global__ void attn_decode_merge_kernel(const float* ws, int nsplit, bf16* out)
 int g_attn_fwd_waves = 8;     // waves per workgroup of the D=128 forward (mm_set_option "attn_fwd_waves": 8 or 4)
 int g_attn_fwd_pf = 1;        // D=128 forward with prefetched fragments (attn_fwd128p_kernel; mm_set_option "attn_fwd_pf" 0 = the older kernel)
 int g_attn_fwd_q = 1;         // D=128 forward with the two waves of a SIMD out of phase (attn_fwd128q_kernel; "attn_fwd_q" 0 = attn_fwd128p_kernel)
+int g_attn_dkv_late = 0;      // paired dK/dV kernel: next tile's DMA issued after the S/dP products ("attn_dkv_late" 0 = at the barrier)
 int g_attn_dkv_rd = 8;        // fragment ring slots of attn_bwd_dkv128_pairp_kernel ("attn_dkv_rd": 8 or 4)
 int g_attn_q_rd = 4;          // fragment ring depth of attn_fwd128q_kernel ("attn_q_rd": 4, 6 or 8)
 int g_attn_diag = 0;          // AttnArgs::diag ("attn_diag")
@@ -2437,13 +2456,13 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
         if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
         grid = dim3((unsigned)nwg);
         const size_t lds = 2 * 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);      // V + K images, rings, row constants
-        if (g_attn_dkv_rd == 4) {
-          (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pairp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          hipLaunchKernelGGL(attn_bwd_dkv128_pairp_kernel<4>, grid, block, lds, s, a);
-        } else {
-          (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pairp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          hipLaunchKernelGGL(attn_bwd_dkv128_pairp_kernel<8>, grid, block, lds, s, a);
-        }
+        auto launch = [&](auto kern) {
+          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+        };
+        if (g_attn_dkv_rd == 4) launch(attn_bwd_dkv128_pairp_kernel<4, false>);
+        else if (g_attn_dkv_late) launch(attn_bwd_dkv128_pairp_kernel<8, true>);
+        else launch(attn_bwd_dkv128_pairp_kernel<8, false>);
       } else {
         const size_t lds = 128 * 256 + 8 * 32 * 256 + 4 * 64 * sizeof(float);
         (void)hipFuncSetAttribute((const void*)attn_bwd_dkv128_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2470,6 +2489,7 @@ int mm_attn_option(const char* name, int value) {   // reached through mm_set_op
   if (!strcmp(name, "attn_fwd_pf")) { g_attn_fwd_pf = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_fwd_q")) { g_attn_fwd_q = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_q_prio")) { g_attn_q_prio = value; return MM_OK; }
+  if (!strcmp(name, "attn_dkv_late")) { g_attn_dkv_late = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_dkv_rd")) { g_attn_dkv_rd = value == 4 ? 4 : 8; return MM_OK; }
   if (!strcmp(name, "attn_q_rd")) { g_attn_q_rd = value; return MM_OK; }
   if (!strcmp(name, "attn_diag")) { g_attn_diag = value; return MM_OK; }

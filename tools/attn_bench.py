@@ -103,9 +103,10 @@ if "--ab-q" in sys.argv:         # D=128 forward: waves of a SIMD in phase (p ke
     sys.exit(0)
 if "--ab-dkv" in sys.argv:       # dK/dV fragment ring: 4 slots vs 8 (same process, interleaved)
     run(4, 2048, 32, 8, 128, True)
-    for rd in (4, 8, 4, 8, 4, 8):
+    for rd, late in ((4, 0), (8, 0), (8, 1), (4, 0), (8, 0), (8, 1), (8, 0), (8, 1)):
         lib().mm_set_option(b"attn_dkv_rd", rd)
-        print("attn_dkv_rd", rd)
+        lib().mm_set_option(b"attn_dkv_late", late)
+        print("attn_dkv_rd", rd, "late", late)
         run(4, 2048, 32, 8, 128, True)
     run(2, 4096, 32, 8, 128, True)
     run(4, 2048, 28, 4, 128, True)
