@@ -992,6 +992,24 @@ __device__ __forceinline__ void imga_lane_patterns(unsigned (&lk)[2], unsigned (
     lv[s2] = (unsigned)((int64_t)rl * v_ss * 2 + cl * 16);
   }
 }
+// the same with NW issuing waves (4 or 8): wave w moves pieces w*PPW .. w*PPW + PPW - 1 of the K tile and of the V tile
+template <int NW>
+__device__ __forceinline__ void imga_issue_kv_n(int w, unsigned st, int row0, const SRsrc& rk, const SRsrc& rv, const unsigned (&lk)[2],
+                                                const unsigned (&lv)[2], int64_t k_ss, int64_t v_ss, int tile_bytes) {
+  constexpr int PPW = 16 / NW;
+  if (w >= NW) return;
+  st += (unsigned)(w * PPW) * 1024u;
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = w * PPW + i, prow = row0 + 8 * (pc >> 1);          // wave-uniform
+    lds_dma16(rk, lk[(pc >> 1) & 1] + (unsigned)((int64_t)prow * k_ss * 2 + (pc & 1) * 128), st + i * 1024);
+  }
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = w * PPW + i, prow = row0 + 8 * (pc >> 1);
+    lds_dma16(rv, lv[(pc >> 1) & 1] + (unsigned)((int64_t)prow * v_ss * 2 + (pc & 1) * 128), st + tile_bytes + i * 1024);
+  }
+}
 __device__ __forceinline__ void imga_issue_kv(int w, unsigned st, int row0, const SRsrc& rk, const SRsrc& rv, const unsigned (&lk)[2],
                                               const unsigned (&lv)[2], int64_t k_ss, int64_t v_ss, int tile_bytes) {
   if (w >= 4) return;
@@ -1174,7 +1192,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128p_kernel(AttnArgs a) {
 #else
 #define MM_QDIAG 0
 #endif
-template <int RD>                      // fragment ring depth: RD - 1 LDS reads in flight ahead of every MFMA
+template <int RD, int NW>              // RD: fragment ring depth (RD - 1 LDS reads in flight ahead of every MFMA); NW: waves issuing the K/V DMA (4 or 8)
 __global__ __launch_bounds__(512, 2) void attn_fwd128q_kernel(AttnArgs a) {
   constexpr int QB = 256, BKV = 64, NDS = 8, NDB = 4, TILE = BKV * 256, NST = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 slots][K 16 KiB | V 16 KiB][key-valid bits: 8 B per key tile]
@@ -1229,7 +1247,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128q_kernel(AttnArgs a) {
   imga_lane_patterns(lk, lv, a.k_ss, a.v_ss);
   auto issue = [&](int t) {
     if (MM_QDIAG & 1) return;
-    imga_issue_kv(w, lds0 + (unsigned)((t & (NST - 1)) * 2 * TILE), t * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
+    imga_issue_kv_n<NW>(w, lds0 + (unsigned)((t & (NST - 1)) * 2 * TILE), t * BKV, rk, rv, lk, lv, a.k_ss, a.v_ss, TILE);
   };
   // wave-uniform: the tile exists, this wave has rows, and the tile is not wholly above the wave's causal diagonal
   auto active = [&](int t) { return t < ntiles && q0 < a.Sq && !(a.causal && t * BKV > q0 + 31 + shift); };
@@ -1327,18 +1345,29 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128q_kernel(AttnArgs a) {
   };
 
   if ((a.prio == 2 && w >= 4) || (a.prio == 3 && w < 4)) __builtin_amdgcn_s_setprio(1);
+  // DMA: an issuing wave has PT = 32 / NW pieces per tile in flight.  With NW = 8 both halves carry half of the issue cost
+  // (a piece costs its wave 100+ cycles of issue time beside the fragment reads); the waits below are no-ops for a wave that
+  // issues nothing (NW = 4: waves 4-7).
+  auto wait_tiles = [&](int in_flight) {          // at most `in_flight` tiles (0, 1 or 2) of this wave's pieces may still be under way
+    if (NW == 8) {
+      if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
+  if (ntiles > 2) issue(2);
+  wait_tiles(ntiles > 2 ? 2 : (ntiles > 1 ? 1 : 0));                      // tile 0 has landed (the early half reads it right
+  __builtin_amdgcn_s_barrier();                                            // after this opening barrier)
   if (w < 4) {
-    // ---- late half: DMA duty.  An issuing wave has 8 pieces per tile in flight.
-    if (ntiles > 0) issue(0);
-    if (ntiles > 1) issue(1);
-    if (ntiles > 2) issue(2);
-    if (ntiles > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // tile 0 has landed (the early half reads it
-    else if (ntiles > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // right after the opening barrier)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // ---- late half
     for (int k = 0; k < ntiles; ++k) {
-      if (k + 2 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // tile k+1 has landed: the early half reads its
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // K in this interval
+      wait_tiles(k + 2 < ntiles ? 1 : 0);                                  // tile k+1 has landed: the early half reads its K now
       __builtin_amdgcn_s_barrier();
       if (k + 3 < ntiles) issue(k + 3);
       if (active(k)) {
@@ -1348,11 +1377,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd128q_kernel(AttnArgs a) {
     }
   } else {
     // ---- early half: its barrier sits between S(k) and softmax(k)
-    __builtin_amdgcn_s_barrier();
     bool act = active(0);
     if (act) seg_s(0);
     for (int k = 0; k < ntiles; ++k) {
+      wait_tiles(k + 2 < ntiles ? 1 : 0);
       __builtin_amdgcn_s_barrier();
+      if (k + 3 < ntiles) issue(k + 3);
       if (act) seg_softmax_pv(k);
       act = active(k + 1);
       if (act) seg_s(k + 1);
@@ -2363,6 +2393,7 @@ int g_attn_fwd_pf = 1;        // D=128 forward with prefetched fragments (attn_f
 int g_attn_fwd_q = 1;         // D=128 forward with the two waves of a SIMD out of phase (attn_fwd128q_kernel; "attn_fwd_q" 0 = attn_fwd128p_kernel)
 int g_attn_dkv_late = 0;      // paired dK/dV kernel: next tile's DMA issued after the S/dP products ("attn_dkv_late" 0 = at the barrier)
 int g_attn_dkv_rd = 8;        // fragment ring slots of attn_bwd_dkv128_pairp_kernel ("attn_dkv_rd": 8 or 4)
+int g_attn_q_issue = 4;       // waves issuing the K/V DMA in attn_fwd128q_kernel ("attn_q_issue": 4 or 8)
 int g_attn_q_rd = 4;          // fragment ring depth of attn_fwd128q_kernel ("attn_q_rd": 4, 6 or 8)
 int g_attn_diag = 0;          // AttnArgs::diag ("attn_diag")
 int g_attn_q_prio = 1;        // s_setprio policy of the out-of-phase kernels (AttnArgs::prio; "attn_q_prio")
@@ -2380,16 +2411,14 @@ int launch_bf16_fwd(const AttnArgs& a, hipStream_t s) {
     const size_t lds = 4 * 2 * 64 * 256 + (size_t)((a.Skv + 63) / 64) * 8;       // K/V ring + key-valid bits
     const int64_t nwg = (int64_t)((a.Sq + 255) / 256) * a.Hq * a.B;
     if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
-    if (g_attn_q_rd == 8) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd128q_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_fwd128q_kernel<8>, dim3((unsigned)nwg), dim3(512), lds, s, a);
-    } else if (g_attn_q_rd == 6) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd128q_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_fwd128q_kernel<6>, dim3((unsigned)nwg), dim3(512), lds, s, a);
-    } else {
-      (void)hipFuncSetAttribute((const void*)attn_fwd128q_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(attn_fwd128q_kernel<4>, dim3((unsigned)nwg), dim3(512), lds, s, a);
-    }
+    auto launch = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), lds, s, a);
+    };
+    if (g_attn_q_rd == 8) launch(attn_fwd128q_kernel<8, 4>);
+    else if (g_attn_q_rd == 6) launch(attn_fwd128q_kernel<6, 4>);
+    else if (g_attn_q_issue == 8) launch(attn_fwd128q_kernel<4, 8>);
+    else launch(attn_fwd128q_kernel<4, 4>);
     MM_CHECK_LAUNCH();
     return MM_OK;
   }
@@ -2491,6 +2520,7 @@ int mm_attn_option(const char* name, int value) {   // reached through mm_set_op
   if (!strcmp(name, "attn_q_prio")) { g_attn_q_prio = value; return MM_OK; }
   if (!strcmp(name, "attn_dkv_late")) { g_attn_dkv_late = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_dkv_rd")) { g_attn_dkv_rd = value == 4 ? 4 : 8; return MM_OK; }
+  if (!strcmp(name, "attn_q_issue")) { g_attn_q_issue = value == 4 ? 4 : 8; return MM_OK; }
   if (!strcmp(name, "attn_q_rd")) { g_attn_q_rd = value; return MM_OK; }
   if (!strcmp(name, "attn_diag")) { g_attn_diag = value; return MM_OK; }
   if (!strcmp(name, "attn_fwd_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_attn_fwd_waves = value; return MM_OK; }

@@ -101,6 +101,15 @@ if "--ab-q" in sys.argv:         # D=128 forward: waves of a SIMD in phase (p ke
     run(4, 2048, 28, 4, 128, True)
     run(4, 2048, 32, 8, 128, True, mask=True)
     sys.exit(0)
+if "--ab-issue" in sys.argv:     # out-of-phase forward: 4 vs 8 waves issuing the K/V DMA (same process, interleaved)
+    run(4, 2048, 32, 8, 128, True)
+    for nw in (4, 8, 4, 8, 4, 8):
+        lib().mm_set_option(b"attn_q_issue", nw)
+        print("attn_q_issue", nw)
+        run(4, 2048, 32, 8, 128, True)
+    run(2, 4096, 32, 8, 128, True)
+    run(4, 2048, 32, 8, 128, True, mask=True)
+    sys.exit(0)
 if "--ab-dkv" in sys.argv:       # dK/dV fragment ring: 4 slots vs 8 (same process, interleaved)
     run(4, 2048, 32, 8, 128, True)
     for rd, late in ((4, 0), (8, 0), (8, 1), (4, 0), (8, 0), (8, 1), (8, 0), (8, 1)):
