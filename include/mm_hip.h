@@ -69,6 +69,12 @@ int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, 
  * bf16 only; MM_ERR_UNSUPPORTED when I % 128, K % 64 or M < 256 (use the two-launch form then).                              */
 int mm_gemm_swiglu_fwd(int dtype, int M, int I, int K, const void* X, int ldx, const void* Wgu, int ldw, void* GU, int ldgu,
                        void* ACT, int ldact, void* stream);
+/* Linear + GELU forward for TRAINING in one launch: ACT = act(X W^T + bias) (+ residual), PRE = the bf16 pre-activation
+ * X W^T + bias that the activation's backward needs (CLIP MLP fc1, HF:clip:368-372; projector, mlp.py:33-39).  epilogue = exactly one
+ * of MM_EPI_GELU_ERF / QUICK_GELU / GELU_TANH, optionally | MM_EPI_BIAS | MM_EPI_RESIDUAL.  Rounding points as in mm_gemm +
+ * mm_gelu_fwd (+ mm_add): bit-identical.  bf16 only, M > 16 (MM_ERR_UNSUPPORTED otherwise: use the separate launches).          */
+int mm_gemm_act_fwd(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* bias,
+                    void* PRE, int ldpre, void* ACT, int ldact, const void* residual, int ldr, int epilogue, void* stream);
 /* backward of down_proj's input and of the SwiGLU in one launch: dGU [M, 2I] = swiglu'(GU) * (dY [M, H] . Wd [H, I]), the
  * product d(act) staying in registers (autograd of HF:llama:163-176; bit-identical to mm_gemm NN + mm_swiglu_bwd).          */
 int mm_gemm_swiglu_bwd(int dtype, int M, int I, int H, const void* dY, int lddy, const void* Wd, int ldw, const void* GU,

@@ -203,6 +203,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
         for (int r = 0; r < 4; ++r)
           if (full || n + r < g.N) v[r] += (float)bias[n + r];
       }
+      const bool keep_pre = g.C2 != nullptr;          // mm_gemm_act_fwd: the pre-activation goes to C2 (backward needs it) and
+      if (keep_pre) {                                   // the arithmetic takes the roundings of the two-launch form (bit-identical)
+        bf16* pp = (bf16*)g.C2 + (int64_t)m * g.ldc2 + n;
+        if (full) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { o[r] = (bf16)v[r]; v[r] = (float)o[r]; }
+          *(bf16x4*)pp = o;
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < g.N) { const bf16 o = (bf16)v[r]; pp[r] = o; v[r] = (float)o; }
+        }
+      }
       if (epi & MM_EPI_GELU_ERF) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = act_gelu_erf(v[r]);
@@ -212,6 +225,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
       } else if (epi & MM_EPI_GELU_TANH) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = act_gelu_tanh(v[r]);
+      }
+      if (keep_pre && (epi & MM_EPI_RESIDUAL)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)(bf16)v[r];       // the activation kernel's store, before the add kernel
       }
       if (epi & MM_EPI_RESIDUAL) {
         const bf16* rp = R + (int64_t)m * g.ldr + n;
@@ -1001,6 +1018,23 @@ extern "C" int mm_gemm_swiglu_fwd(int dtype, int M, int I, int K, const void* X,
   if (dtype != MM_BF16 || (I & 127) || (K & 63) || M < 256) return MM_ERR_UNSUPPORTED;
   if ((ldgu & 3) || (ldact & 3) || (((uintptr_t)ACT) & 7) || (int64_t)2 * I * ldw * 2 >= 0xFFFFFFFFll) return MM_ERR_ALIGN;
   GemmArgs g{M, 2 * I, K, X, ldx, Wgu, ldw, GU, ldgu, nullptr, nullptr, 0, 0, 0, 0, 0, I, ACT, ldact, nullptr, 0};
+  return gemm_launch(g, dtype, MM_GEMM_NT, (hipStream_t)stream);
+}
+
+// y = act(x W^T + b) (+ residual) with the bf16 pre-activation kept in PRE for backward: the forward of a Linear + GELU in ONE
+// launch where training used three (GEMM, activation, add).  Roundings as in that form: bit-identical results.
+extern "C" int mm_gemm_act_fwd(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* bias,
+                               void* PRE, int ldpre, void* ACT, int ldact, const void* residual, int ldr, int epilogue, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0) return MM_ERR_ARG;
+  if (M == 0) return MM_OK;
+  if (!X || !W || !PRE || !ACT) return MM_ERR_ARG;
+  if ((epilogue & MM_EPI_BIAS) && !bias) return MM_ERR_ARG;
+  if ((epilogue & MM_EPI_RESIDUAL) && !residual) return MM_ERR_ARG;
+  const int acts = epilogue & (MM_EPI_GELU_ERF | MM_EPI_QUICK_GELU | MM_EPI_GELU_TANH);
+  if (!acts || (acts & (acts - 1)) || (epilogue & ~(acts | MM_EPI_BIAS | MM_EPI_RESIDUAL))) return MM_ERR_ARG;
+  if (dtype != MM_BF16 || M <= 16) return MM_ERR_UNSUPPORTED;       // the fp32 path and the decode GEMM keep the separate passes
+  if ((ldpre & 3) || (((uintptr_t)PRE) & 7)) return MM_ERR_ALIGN;
+  GemmArgs g{M, N, K, X, ldx, W, ldw, ACT, ldact, bias, residual, ldr, epilogue, 0, 0, 0, 0, PRE, ldpre, nullptr, 0};
   return gemm_launch(g, dtype, MM_GEMM_NT, (hipStream_t)stream);
 }
 

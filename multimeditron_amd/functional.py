@@ -164,10 +164,14 @@ class LinearFn(torch.autograd.Function):
         b = bg.tensor() if bg is not None else None
         pre = None
         if act and (x.requires_grad or wg.requires_grad):
-            pre = K.linear_fwd(x, w, bias=b)                      # keep the pre-activation for backward
-            y = K.gelu_fwd(pre, GELU_KIND[act])
-            if residual is not None:
-                y = K.add(y, residual)
+            fused = K.linear_act_fwd(x, w, b, act, residual)      # one launch: the epilogue writes the pre-activation AND the output
+            if fused is not None:
+                pre, y = fused
+            else:
+                pre = K.linear_fwd(x, w, bias=b)                  # keep the pre-activation for backward
+                y = K.gelu_fwd(pre, GELU_KIND[act])
+                if residual is not None:
+                    y = K.add(y, residual)
         else:
             y = K.linear_fwd(x, w, bias=b, residual=residual, act=act, ldc_pad=ldc_pad)
         ctx.wg, ctx.bg, ctx.act = wg, bg, act

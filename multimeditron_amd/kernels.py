@@ -77,6 +77,23 @@ def linear_fwd(x2d, w, bias=None, residual=None, act=0, ldc_pad=False):
     return gemm(GEMM_NT, x2d, w, M, N, K, bias=bias, residual=residual, act=act, ldc_pad=ldc_pad)
 
 
+def linear_act_fwd(x2d, w, bias, act, residual=None):
+    """Training forward of Linear + GELU in one launch: -> (pre, y) with pre = bf16(x @ w^T + bias) kept for backward and
+    y = act(pre) (+ residual).  Bit-identical to linear_fwd + gelu_fwd (+ add).  bf16 and M > 16 only: the caller falls back to the
+    separate launches otherwise (this function returns None then)."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    if x2d.dtype != torch.bfloat16 or M <= 16 or _os.environ.get("MM_FUSED_GELU", "1") == "0":
+        return None
+    assert x2d.stride(1) == 1 and w.stride(1) == 1
+    pre = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    y = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    epi = act | (EPI_BIAS if bias is not None else 0) | (EPI_RESIDUAL if residual is not None else 0)
+    call("mm_gemm_act_fwd", dt(x2d), M, N, K, _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(pre), pre.stride(0), _p(y),
+         y.stride(0), _p(residual), residual.stride(0) if residual is not None else 0, epi, _stream())
+    return pre, y
+
+
 def linear_dgrad(dy2d, w, out=None):
     """dx[M,K] = dy[M,N] @ w[N,K]."""
     M = dy2d.shape[0]

@@ -720,3 +720,28 @@ def test_embedding_out_of_range_id_raises(K):      # noqa: F811
     neg[0] = -1
     with pytest.raises(IndexError):
         K.embed_check_ids(neg, 50, block=True)
+
+
+@pytest.mark.parametrize("act_name", ["EPI_GELU_ERF", "EPI_QUICK_GELU", "EPI_GELU_TANH"])
+@pytest.mark.parametrize("shape", [(1028, 4096, 1024, True), (300, 136, 72, False), (4112, 3584, 1152, True)])
+def test_linear_gelu_keeps_preactivation_bit_identical(K, act_name, shape):      # noqa: F811
+    """mm_gemm_act_fwd (training forward of Linear + GELU in one launch) against the three launches it replaces: the
+    pre-activation kept for backward and the output are bit-identical (ViT-L fc1, a ragged shape, SigLIP fc1; with residual)."""
+    from multimeditron_amd import _lib
+    act = getattr(_lib, act_name)
+    M, N, Kd, with_res = shape
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(M, Kd, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, Kd, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16) if with_res else None
+    pre_ref = K.linear_fwd(x, w, bias=b)
+    y_ref = K.gelu_fwd(pre_ref, _lib.GELU_KIND[act])
+    if res is not None:
+        y_ref = K.add(y_ref, res)
+    fused = K.linear_act_fwd(x, w, b, act, res)
+    assert fused is not None
+    pre, y = fused
+    torch.cuda.synchronize()
+    assert torch.equal(pre, pre_ref)
+    assert torch.equal(y, y_ref)
