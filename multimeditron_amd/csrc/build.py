@@ -37,10 +37,20 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        # -Rpass-analysis=kernel-resource-usage: registers / scratch / LDS of every kernel, kept beside the object
+        # (<obj>.resources.txt): tests/test_no_spills_cpu.py fails the build of a hot kernel that started to spill
+        cmd = [HIPCC] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        remarks = [ln for ln in r.stderr.splitlines() if "remark:" in ln]
+        other = [ln for ln in r.stderr.splitlines() if "remark:" not in ln and "-Rpass-analysis" not in ln]
+        if other:
+            sys.stderr.write("\n".join(other) + "\n")
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        with open(o + ".resources.txt", "w") as f:
+            f.write("\n".join(remarks) + "\n")
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))

@@ -161,7 +161,10 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
 }
 
 // epilogue shared by the bf16 kernels: acc[i][j][r] = C[mw + i*16 + (l&15)][nw + j*16 + 4*(l>>4) + r]
-template <int MREP, int NREP>
+// ALLOW_PRE: compile the pre-activation store of mm_gemm_act_fwd into this instantiation.  Only the small-tile DMA kernels get it:
+// in the 256x256 kernel (128 accumulator registers per lane) the extra path cost 528 bytes of scratch per lane and 10 % of the
+// GEMM's speed for EVERY launch -- found by the step going from 401 to 440 ms.
+template <int MREP, int NREP, bool ALLOW_PRE = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, float& ss) {
   const int l = threadIdx.x & 63;
   bf16* C = (bf16*)g.C;
@@ -203,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
         for (int r = 0; r < 4; ++r)
           if (full || n + r < g.N) v[r] += (float)bias[n + r];
       }
-      const bool keep_pre = g.C2 != nullptr;          // mm_gemm_act_fwd: the pre-activation goes to C2 (backward needs it) and
+      const bool keep_pre = ALLOW_PRE && g.C2 != nullptr;   // mm_gemm_act_fwd: the pre-activation goes to C2 (backward needs it) and
       if (keep_pre) {                                   // the arithmetic takes the roundings of the two-launch form (bit-identical)
         bf16* pp = (bf16*)g.C2 + (int64_t)m * g.ldc2 + n;
         if (full) {
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
       }
     }
     if (swi) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
-    else gemm_epilogue<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN), ss);
+    else gemm_epilogue<MREP, NREP, (BM_ * BN_ <= 128 * 128)>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN), ss);
     tile = next;
     m0 = nm0;
     n0 = nn0;
@@ -1103,8 +1106,13 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t
     const int64_t tiles_128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
     const int64_t tiles_256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     int variant = 0;   // 0 = v1 (128x128 register staged); DMA tiles: 1 = 256x128, 2 = 256x256, 3 = 128x128, 4 = 64x128, 5 = 64x64
+    const bool keep_pre = g.C2 != nullptr && !g.swi_I;      // mm_gemm_act_fwd: compiled into the small-tile DMA kernels only
     if (g.swi_I) variant = 2;                 // the fused gate|up tile is defined on the 256x256 kernel only
-    else if (fits32) {
+    else if (keep_pre) {
+      if (!fits32 || forced == 1) return MM_ERR_UNSUPPORTED;
+      variant = (forced >= 4 && forced <= 6) ? forced - 1 : small_variant(M, N, K);
+      if (variant < 3) variant = 3;           // a problem that would take a 256-wide tile: 128x128 (the caller may prefer the separate launches)
+    } else if (fits32) {
       if (forced >= 2 && forced <= 6) variant = forced - 1;
       else if (forced == 0 && tiles_128 >= 192) variant = MM_DEFAULT_DMA_VARIANT(tiles_256);
       else if (forced == 0) variant = small_variant(M, N, K);

@@ -1,0 +1,44 @@
+"""Build hygiene (CPU): the hot kernels must not spill.  `multimeditron_amd/csrc/build.py` keeps hipcc's per-kernel resource
+remarks beside every object (`csrc/build/*.o.resources.txt`); a kernel on the step's critical path that starts to use scratch
+loses far more than the change that caused it gains (round 2: an extra epilogue path put 528 bytes/lane of scratch into the
+256x256 GEMM and cost 10 % of the step).  Skipped when the library has not been built in this tree."""
+import os
+import re
+
+import pytest
+
+BUILD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multimeditron_amd", "csrc", "build")
+HOT = {
+    "mm_gemm.o.resources.txt": ["gemm_bf16_dma_kernel", "gemm_bf16_kernel", "gemm_skinny_kernel"],
+    "mm_attn.o.resources.txt": ["attn_fwd128q_kernel", "attn_fwd128p_kernel", "attn_bwd_dq128p_kernel", "attn_bwd_dkv128_pairp_kernel",
+                                "attn_decode_partial_kernel"],
+    "mm_optim.o.resources.txt": ["adamw_kernel", "sumsq_kernel"],
+}
+
+
+def _kernels(path):
+    out, name = [], None
+    for ln in open(path):
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", ln)
+        if m and name:
+            out.append((name, int(m.group(1))))
+    return out
+
+
+@pytest.mark.parametrize("fname", sorted(HOT))
+def test_hot_kernels_use_no_scratch(fname):
+    path = os.path.join(BUILD, fname)
+    if not os.path.exists(path):
+        pytest.skip("library not built in this tree (python multimeditron_amd/csrc/build.py)")
+    ks = _kernels(path)
+    assert ks, path
+    seen = set()
+    for name, scratch in ks:
+        for hot in HOT[fname]:
+            if hot in name:
+                seen.add(hot)
+                assert scratch == 0, f"{name}: {scratch} bytes/lane of scratch"
+    assert seen == set(HOT[fname]), sorted(set(HOT[fname]) - seen)
