@@ -80,12 +80,12 @@ int mm_gemm_act_fwd(int dtype, int M, int N, int K, const void* X, int ldx, cons
 int mm_gemm_swiglu_bwd(int dtype, int M, int I, int H, const void* dY, int lddy, const void* Wd, int ldw, const void* GU,
                        int ldgu, void* dGU, int lddgu, void* stream);
 
-/* a GEMM that also returns the sum of squares of what it stores: the launch overwrites the first n <= capacity partials (one
- * float per wave) and leaves the others alone; on a buffer the caller zeroed beforehand they sum to sum(C^2) over the bf16
- * values written (after MM_EPI_ACCUMULATE, the only epilogue allowed).
- * Used for the weight gradients so that the global gradient norm of `max_grad_norm` clipping (config_alignment.yaml:49 ->
- * HF Trainer -> torch.nn.utils.clip_grad_norm_) needs no second pass over 16.7 GB of gradients.  Deterministic: fixed slot
- * per wave, no atomics.  mm_gemm_sumsq_slots -> the capacity to provide for a problem (upper bound over the launch forms). */
+/* a GEMM that also returns the sum of squares of what it stores: the call overwrites the first n <= capacity partials and leaves
+ * the others alone; on a buffer the caller zeroed beforehand they sum to sum(C^2) over the bf16 values written (after
+ * MM_EPI_ACCUMULATE, the only epilogue allowed).  For the weight gradients, so that the global gradient norm of `max_grad_norm`
+ * clipping (config_alignment.yaml:49 -> HF Trainer -> torch.nn.utils.clip_grad_norm_) can be assembled per GEMM.  Deterministic:
+ * fixed slot per workgroup, no atomics.  Implemented as the GEMM followed by a reduction pass over C (the in-epilogue form cost
+ * every GEMM more than it saved: csrc/mm_gemm.hip).  mm_gemm_sumsq_slots -> the capacity to provide for a problem.               */
 int mm_gemm_sumsq_slots(int dtype, int layout, int M, int N, int K, int64_t* slots);
 int mm_gemm_sumsq(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                   int epilogue, float* partials, int64_t capacity, void* stream);

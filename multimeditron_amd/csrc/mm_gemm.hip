@@ -46,9 +46,6 @@ struct GemmArgs {
   int swi_I;
   void* C2; int ldc2;
   const void* aux; int ldaux;   // MM_EPI_SWIGLU_BWD: the saved pre-activations [M, 2I]
-  // mm_gemm_sumsq: every wave adds up the squares of the (rounded) values it stores and writes ONE float to
-  // sumsq[workgroup * waves + wave] when the workgroup is done -- the global gradient norm without re-reading 16.7 GB
-  float* sumsq;
 };
 constexpr int MM_EPI_SWIGLU_BWD = 1 << 20;   // internal epilogue flag (mm_gemm_swiglu_bwd), not part of the ABI enum
 
@@ -164,8 +161,8 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
 // ALLOW_PRE: compile the pre-activation store of mm_gemm_act_fwd into this instantiation.  Only the small-tile DMA kernels get it:
 // in the 256x256 kernel (128 accumulator registers per lane) the extra path cost 528 bytes of scratch per lane and 10 % of the
 // GEMM's speed for EVERY launch -- found by the step going from 401 to 440 ms.
-template <int MREP, int NREP, bool ALLOW_PRE = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, float& ss) {
+template <int MREP, int NREP, bool ALLOW_PRE>
+__device__ __forceinline__ void gemm_epilogue_plain(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
   const int l = threadIdx.x & 63;
   bf16* C = (bf16*)g.C;
   const bf16* bias = (const bf16*)g.bias;
@@ -181,25 +178,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
       if (n >= g.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       const bool full = (n + 3) < g.N;
-      if (epi & MM_EPI_SWIGLU_BWD) {
-        // C = d(gate|up) [M, 2N]; acc = d(act) [M, N] (down_proj's input gradient); aux = saved gate|up.  Same arithmetic and
-        // rounding points as down_proj dgrad (bf16 store) followed by swiglu_bwd_kernel: N % 4 == 0 is checked by the host.
-        const bf16* gp = (const bf16*)g.aux + (int64_t)m * g.ldaux + n;
-        const bf16x4 gv = *(const bf16x4*)gp, uv = *(const bf16x4*)(gp + g.N);
-        bf16x4 dg, du;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float gf = (float)gv[r], sig = 1.0f / (1.0f + __expf(-gf));
-          const float sg = gf * sig;
-          const float dd = (float)(bf16)v[r];
-          du[r] = (bf16)(dd * sg);
-          dg[r] = (bf16)(dd * (float)uv[r] * (sig * (1.0f + gf * (1.0f - sig))));
-        }
-        bf16* dp = C + (int64_t)m * g.ldc + n;
-        *(bf16x4*)dp = dg;
-        *(bf16x4*)(dp + g.N) = du;
-        continue;
-      }
       bf16* cp = C + (int64_t)m * g.ldc + n;
       if (epi & MM_EPI_BIAS) {
 #pragma unroll
@@ -257,21 +235,77 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MR
       if (full) {
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { o[r] = (bf16)v[r]; const float q = (float)o[r]; ss = __builtin_fmaf(q, q, ss); }
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
         *(bf16x4*)cp = o;      // default cache policy: non-temporal stores here measured -4 % (tools/build_diag.sh)
       } else {
         for (int r = 0; r < 4; ++r)
-          if (n + r < g.N) { const bf16 o = (bf16)v[r]; cp[r] = o; const float q = (float)o; ss = __builtin_fmaf(q, q, ss); }
+          if (n + r < g.N) cp[r] = (bf16)v[r];
       }
     }
   }
 }
 
-// one float per wave: the sum of squares of everything this wave stored (mm_gemm_sumsq); fixed slot, no atomics
-__device__ __forceinline__ void flush_sumsq(const GemmArgs& g, float ss, int nwaves) {
-  if (!g.sumsq) return;
-  ss = wave_sum(ss);
-  if ((threadIdx.x & 63) == 0) g.sumsq[(int64_t)blockIdx.x * nwaves + (threadIdx.x >> 6)] = ss;
+// MM_EPI_SWIGLU_BWD (mm_gemm_swiglu_bwd) as its own epilogue: kept out of the plain one, whose instruction count and register
+// pressure every GEMM launch pays for.
+template <int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+  const int l = threadIdx.x & 63;
+  bf16* C = (bf16*)g.C;
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    const int m = mw + i * 16 + (l & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const int n = nw + j * 16 + 4 * (l >> 4);
+      if (n >= g.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      // C = d(gate|up) [M, 2N]; acc = d(act) [M, N] (down_proj's input gradient); aux = saved gate|up.  Same arithmetic and
+      // rounding points as down_proj dgrad (bf16 store) followed by swiglu_bwd_kernel: N % 4 == 0 is checked by the host.
+      const bf16* gp = (const bf16*)g.aux + (int64_t)m * g.ldaux + n;
+      const bf16x4 gv = *(const bf16x4*)gp, uv = *(const bf16x4*)(gp + g.N);
+      bf16x4 dg, du;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gf = (float)gv[r], sig = 1.0f / (1.0f + __expf(-gf));
+        const float sg = gf * sig;
+        const float dd = (float)(bf16)v[r];
+        du[r] = (bf16)(dd * sg);
+        dg[r] = (bf16)(dd * (float)uv[r] * (sig * (1.0f + gf * (1.0f - sig))));
+      }
+      bf16* dp = C + (int64_t)m * g.ldc + n;
+      *(bf16x4*)dp = dg;
+      *(bf16x4*)(dp + g.N) = du;
+    }
+  }
+}
+
+// runtime dispatch between the two (the register-staged 128x128 kernel, which the step does not run; the LDS-DMA kernels pick
+// their epilogue at compile time, see EK)
+template <int MREP, int NREP, bool ALLOW_PRE = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+  if (g.epi & MM_EPI_SWIGLU_BWD) gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, mw, nw);
+  else gemm_epilogue_plain<MREP, NREP, ALLOW_PRE>(g, acc, mw, nw);
+}
+
+// sum of squares of a bf16 [M, N] matrix with leading dimension ld -> partial[blockIdx.x] (mm_gemm_sumsq's second pass)
+__global__ __launch_bounds__(256) void sumsq2d_kernel(const bf16* C, int M, int N, int ld, float* partial) {
+  __shared__ float red[8];
+  float s = 0.f;
+  const int64_t nv = (int64_t)M * (N / 4);                   // N % 4 == 0 is guaranteed by ldc % 4 == 0 ... checked by the host
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / (N / 4), c = (i % (N / 4)) * 4;
+    const bf16x4 v = *(const bf16x4*)(C + r * ld + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s = __builtin_fmaf((float)v[k], (float)v[k], s);
+  }
+  if ((N & 3) && blockIdx.x == 0)
+    for (int64_t i = threadIdx.x; i < (int64_t)M * (N & 3); i += 256) {
+      const float q = (float)C[(i / (N & 3)) * ld + (N & ~3) + i % (N & 3)];
+      s = __builtin_fmaf(q, q, s);
+    }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 template <bool A_KC, bool B_KC>
@@ -327,9 +361,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  float ss = 0.f;
-  gemm_epilogue<4, 4>(g, acc, m0 + wm * 64, n0 + wn * 64, ss);
-  flush_sumsq(g, ss, 4);
+  gemm_epilogue<4, 4>(g, acc, m0 + wm * 64, n0 + wn * 64);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -549,7 +581,7 @@ __device__ __forceinline__ bf16x8 frag_load2(const char* tile, int xb, int ks) {
 
 // BMxBN block tile, 8 waves as WGM x WGN, STAGES-deep LDS ring (3: counted vmcnt keeps one tile in flight across the
 // barrier; 2: the next tile's DMA is issued right after the barrier and has one whole compute phase to land).
-template <bool A_KC, bool B_KC, int BM_, int BN_, int WGM, int STAGES, int ISSUE_WAVES>
+template <bool A_KC, bool B_KC, int BM_, int BN_, int WGM, int STAGES, int ISSUE_WAVES, int EK = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   constexpr int WGN = 8 / WGM;
   constexpr int MREP = BM_ / WGM / 16, NREP = BN_ / WGN / 16;
@@ -575,7 +607,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   int tile = blockIdx.x;
   int pm = 0, pn = 0;
   if (tile < total_full) block_to_tile(tile, g.nbm, g.nbn, pm, pn);
-  const int swi = (B_KC && BN_ == 256 && WGM == 2) ? g.swi_I : 0;       // fused SwiGLU: a tile = 128 features (gate + up)
+  // EK (epilogue kind) is a TEMPLATE parameter: 0 plain, 2 SwiGLU backward (mm_gemm_swiglu_bwd, NN), 3 fused gate|up
+  // (mm_gemm_swiglu_fwd, NT 256x256).  With the rare epilogues inlined behind runtime branches every GEMM of the step ran
+  // 1.6 % slower than the round-1 library on the same box (tools/gemm_bench.py, 15 shapes); with them in their own
+  // instantiations the plain kernel is the round-1 kernel again.
+  const int swi = (EK == 3) ? g.swi_I : 0;                               // fused SwiGLU: a tile = 128 features (gate + up)
   const int nstep = swi ? BN_ / 2 : BN_;
   int m0 = pm * BM_, n0 = pn * nstep;
   SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
@@ -602,7 +638,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
     dma_tile<B_KC, BN_, ISSUE_WAVES>(st + A_BYTES, db, g.ldb, t * G_BK, g.K, swi);
   };
   static_assert(STAGES == 2, "the persistent stream below is written for the 2-stage ring");
-  float ss = 0.f;                                                     // sum of squares of this wave's stores (mm_gemm_sumsq)
   int sidx = 0;                                                       // global K-step counter (ring position)
   if (tile < total_full) issue(ra, rb, 0, 0);
   while (tile < total_full) {
@@ -670,8 +705,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
         }
       }
     }
-    if (swi) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
-    else gemm_epilogue<MREP, NREP, (BM_ * BN_ <= 128 * 128)>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN), ss);
+    if constexpr (EK == 3) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
+    else if constexpr (EK == 2) gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    else gemm_epilogue_plain<MREP, NREP, (BM_ * BN_ <= 128 * 128)>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     tile = next;
     m0 = nm0;
     n0 = nn0;
@@ -742,10 +778,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      gemm_epilogue<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN), ss);
+      if constexpr (EK == 2) gemm_epilogue_swiglu_bwd<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
+      else gemm_epilogue_plain<MREP, NREPH, false>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
     }
   }
-  flush_sumsq(g, ss, 8);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -994,9 +1030,7 @@ extern "C" int mm_get_option(const char* name, int* value) {
   return MM_ERR_ARG;
 }
 
-// slots: when non-null nothing is launched and *slots receives an upper bound of the sum-of-squares partials a launch of this
-// problem may write (16 per tile of the variant it would take); slot_cap: capacity of g.sumsq (checked before the launch)
-static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t* slots = nullptr, int64_t slot_cap = 0);
+static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s);
 
 extern "C" int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                        int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream) {
@@ -1054,19 +1088,22 @@ extern "C" int mm_gemm_swiglu_bwd(int dtype, int M, int I, int H, const void* dY
   return gemm_launch(g, dtype, MM_GEMM_NN, (hipStream_t)stream);
 }
 
-// C = A.B (any layout, MM_EPI_ACCUMULATE allowed) and, in the same pass, the sum of squares of the stored bf16 values:
-// the launch OVERWRITES partials[0 .. n) (n = its workgroups x waves <= capacity), one float per wave, and leaves the rest
-// alone: the caller zeroes the buffer once (per step) so that sum(partials[0 .. capacity)) = sum(C^2).  The weight-gradient GEMMs use
-// it so that clip_grad_norm_'s global norm (reference config_alignment.yaml:49, HF Trainer) costs no second pass over the
-// gradients.  mm_gemm_sumsq_slots gives the capacity to provide.  bf16 only; not for M <= 16 NT (decode) problems.
+// C = A.B (any layout, MM_EPI_ACCUMULATE allowed) followed by the sum of squares of the stored bf16 values: partials[0 .. n)
+// (n = mm_gemm_sumsq_slots <= capacity) are OVERWRITTEN, the rest is left alone; the caller zeroes the buffer once so that
+// sum(partials[0 .. capacity)) = sum(C^2) (clip_grad_norm_'s global norm assembled per weight-gradient GEMM, reference
+// config_alignment.yaml:49).  Round 2 first computed the sum INSIDE the GEMM epilogue (one FMA per stored element, a slot per
+// wave): that made the gradient-norm sweep unnecessary but lengthened every wgrad GEMM by more than the sweep costs
+// (399.6 vs 395.5 ms/step), and merely compiling the path into the kernel cost every OTHER GEMM 1.6 %.  It is a second,
+// bandwidth-bound pass over C now (C is L2/MALL-hot right after the GEMM); same ABI, same results up to summation order.
+static int sumsq_blocks(int64_t M, int64_t N) {
+  const int64_t v = (M * N / 4 + 255) / 256;
+  return (int)(v < 1 ? 1 : (v > 1024 ? 1024 : v));
+}
 extern "C" int mm_gemm_sumsq_slots(int dtype, int layout, int M, int N, int K, int64_t* slots) {
   if (!slots || M <= 0 || N <= 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;
   if (dtype != MM_BF16) return MM_ERR_UNSUPPORTED;
-  GemmArgs g{M, N, K, (const void*)16, (K + 7) / 8 * 8, (const void*)16, (K + 7) / 8 * 8, (void*)16, (N + 7) / 8 * 8};
-  if (layout == MM_GEMM_NN) g.ldb = (N + 7) / 8 * 8;
-  if (layout == MM_GEMM_TN) { g.lda = (M + 7) / 8 * 8; g.ldb = (N + 7) / 8 * 8; }
-  g.sumsq = (float*)16;
-  return gemm_launch(g, dtype, layout, nullptr, slots, 0);
+  *slots = sumsq_blocks(M, N);
+  return MM_OK;
 }
 
 extern "C" int mm_gemm_sumsq(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
@@ -1075,12 +1112,17 @@ extern "C" int mm_gemm_sumsq(int dtype, int layout, int M, int N, int K, const v
   if (dtype != MM_BF16) return MM_ERR_UNSUPPORTED;
   if (!A || !B || !C || !partials || capacity <= 0 || (epilogue & ~MM_EPI_ACCUMULATE)) return MM_ERR_ARG;
   if (M == 0 || N == 0) return hipMemsetAsync(partials, 0, (size_t)capacity * sizeof(float), (hipStream_t)stream) == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
+  const int nb = sumsq_blocks(M, N);
+  if (capacity < nb) return MM_ERR_ARG;
   GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, epilogue};
-  g.sumsq = partials;
-  return gemm_launch(g, dtype, layout, (hipStream_t)stream, nullptr, capacity);
+  const int rc = gemm_launch(g, dtype, layout, (hipStream_t)stream);
+  if (rc != MM_OK) return rc;
+  hipLaunchKernelGGL(sumsq2d_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16*)C, M, N, ldc, partials);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
 }
 
-static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t* slots, int64_t slot_cap) {
+static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
   const int M = g.M, N = g.N, K = g.K, lda = g.lda, ldb = g.ldb, ldc = g.ldc, ldr = g.ldr, epilogue = g.epi;
   const void *A = g.A, *B = g.B;
   void* C = g.C;
@@ -1094,7 +1136,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t
       return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'b' ? 3 : 2));
     }();
     const int forced = g_opt_kernel ? g_opt_kernel : forced_env;
-    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 && !g.swi_I && !g.sumsq &&
+    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 && !g.swi_I &&
         (int64_t)16 * lda * 2 < 0xFFFFFFFFll && (int64_t)16 * ldb * 2 < 0xFFFFFFFFll) {   // decode: stream W once
       dim3 grid((unsigned)((N + 15) / 16)), block(512);
       hipLaunchKernelGGL(gemm_skinny_kernel, grid, block, 0, s, g);
@@ -1124,7 +1166,6 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t
       g.nbn = g.swi_I ? g.swi_I / 128 : (N + bn - 1) / bn;
       const int64_t nwg = (int64_t)g.nbm * g.nbn;
       if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
-      if (slots) { *slots = 16 * nwg; return MM_OK; }      // 8 waves x (tiles, or two half-tile workgroups per tile)
       const size_t lds = 2 * (bm + bn) * G_BK * 2;
       static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
       // persistent: one resident workgroup per CU walks the tiles; otherwise one tile each
@@ -1136,7 +1177,6 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t
           nblk = nwg >= ncu ? ncu : 2 * rem;
         }
       }
-      if (g.sumsq && slot_cap < nblk * 8) return MM_ERR_ARG;       // slots beyond nblk*8 are left as they are (see mm_hip.h)
       dim3 grid((unsigned)nblk), block(512);
 #define MM_LAUNCH_ONE(...)                                                                                               \
   do {                                                                                                                   \
@@ -1144,19 +1184,29 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     hipLaunchKernelGGL(kfn, grid, block, lds, s, g);                                                                     \
   } while (0)
-#define MM_LAUNCH_DMA(AKC, BKC)                                                                                          \
+#define MM_LAUNCH_DMA(AKC, BKC, EK)                                                                                      \
   do {                                                                                                                   \
-    if (variant == 1) MM_LAUNCH_ONE(AKC, BKC, 256, 128, 4, 2, 8);                                                        \
-    else if (variant == 3) MM_LAUNCH_ONE(AKC, BKC, 128, 128, 2, 2, 4);                                                   \
-    else if (variant == 4) MM_LAUNCH_ONE(AKC, BKC, 64, 128, 2, 2, 4);                                                    \
-    else if (variant == 5) MM_LAUNCH_ONE(AKC, BKC, 64, 64, 2, 2, 4);                                                     \
-    else if (g_opt_issue_waves == 4) MM_LAUNCH_ONE(AKC, BKC, 256, 256, 2, 2, 4);                                         \
-    else MM_LAUNCH_ONE(AKC, BKC, 256, 256, 2, 2, 8);                                                                     \
+    if (variant == 1) MM_LAUNCH_ONE(AKC, BKC, 256, 128, 4, 2, 8, EK);                                                    \
+    else if (variant == 3) MM_LAUNCH_ONE(AKC, BKC, 128, 128, 2, 2, 4, EK);                                               \
+    else if (variant == 4) MM_LAUNCH_ONE(AKC, BKC, 64, 128, 2, 2, 4, EK);                                                \
+    else if (variant == 5) MM_LAUNCH_ONE(AKC, BKC, 64, 64, 2, 2, 4, EK);                                                 \
+    else if (g_opt_issue_waves == 4) MM_LAUNCH_ONE(AKC, BKC, 256, 256, 2, 2, 4, EK);                                     \
+    else MM_LAUNCH_ONE(AKC, BKC, 256, 256, 2, 2, 8, EK);                                                                 \
   } while (0)
-      switch (layout) {
-        case MM_GEMM_NT: MM_LAUNCH_DMA(true, true); break;
-        case MM_GEMM_NN: MM_LAUNCH_DMA(true, false); break;
-        default: MM_LAUNCH_DMA(false, false); break;
+      // epilogue kind = kernel instantiation: the SwiGLU ones exist for the layout their entry point uses only
+      if (g.swi_I) {                                                      // mm_gemm_swiglu_fwd: NT, 256x256 (variant 2 above)
+        if (layout != MM_GEMM_NT) return MM_ERR_ARG;
+        if (g_opt_issue_waves == 4) MM_LAUNCH_ONE(true, true, 256, 256, 2, 2, 4, 3);
+        else MM_LAUNCH_ONE(true, true, 256, 256, 2, 2, 8, 3);
+      } else if (epilogue & MM_EPI_SWIGLU_BWD) {                          // mm_gemm_swiglu_bwd: NN
+        if (layout != MM_GEMM_NN) return MM_ERR_ARG;
+        MM_LAUNCH_DMA(true, false, 2);
+      } else {
+        switch (layout) {
+          case MM_GEMM_NT: MM_LAUNCH_DMA(true, true, 0); break;
+          case MM_GEMM_NN: MM_LAUNCH_DMA(true, false, 0); break;
+          default: MM_LAUNCH_DMA(false, false, 0); break;
+        }
       }
 #undef MM_LAUNCH_ONE
 #undef MM_LAUNCH_DMA
@@ -1165,8 +1215,6 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t
       g.nbn = (N + BN - 1) / BN;
       const int64_t nwg = (int64_t)g.nbm * g.nbn;
       if (nwg > 0x7FFFFFFF) return MM_ERR_ARG;
-      if (slots) { *slots = 4 * nwg; return MM_OK; }
-      if (g.sumsq && slot_cap < nwg * 4) return MM_ERR_ARG;
       const size_t lds = 4 * TILE_BYTES;
       dim3 grid((unsigned)nwg), block(256);
       switch (layout) {
@@ -1176,7 +1224,6 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s, int64_t
       }
     }
   } else if (dtype == MM_F32) {
-    if (g.sumsq || slots) return MM_ERR_UNSUPPORTED;
     g.nbm = (M + 63) / 64;
     g.nbn = (N + 63) / 64;
     dim3 grid((unsigned)(g.nbm * g.nbn)), block(256);
