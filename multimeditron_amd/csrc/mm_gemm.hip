@@ -161,7 +161,7 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
 // ALLOW_PRE: compile the pre-activation store of mm_gemm_act_fwd into this instantiation.  Only the small-tile DMA kernels get it:
 // in the 256x256 kernel (128 accumulator registers per lane) the extra path cost 528 bytes of scratch per lane and 10 % of the
 // GEMM's speed for EVERY launch -- found by the step going from 401 to 440 ms.
-template <int MREP, int NREP, bool ALLOW_PRE>
+template <int MREP, int NREP, bool ALLOW_PRE, bool ACT = true>
 __device__ __forceinline__ void gemm_epilogue_plain(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
   const int l = threadIdx.x & 63;
   bf16* C = (bf16*)g.C;
@@ -197,15 +197,17 @@ __device__ __forceinline__ void gemm_epilogue_plain(const GemmArgs& g, f32x4 (&a
             if (n + r < g.N) { const bf16 o = (bf16)v[r]; pp[r] = o; v[r] = (float)o; }
         }
       }
-      if (epi & MM_EPI_GELU_ERF) {
+      if (ACT) {                                        // EK == 1 instantiations only (NT: a forward Linear with an activation)
+        if (epi & MM_EPI_GELU_ERF) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_gelu_erf(v[r]);
-      } else if (epi & MM_EPI_QUICK_GELU) {
+          for (int r = 0; r < 4; ++r) v[r] = act_gelu_erf(v[r]);
+        } else if (epi & MM_EPI_QUICK_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_quick_gelu(v[r]);
-      } else if (epi & MM_EPI_GELU_TANH) {
+          for (int r = 0; r < 4; ++r) v[r] = act_quick_gelu(v[r]);
+        } else if (epi & MM_EPI_GELU_TANH) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = act_gelu_tanh(v[r]);
+          for (int r = 0; r < 4; ++r) v[r] = act_gelu_tanh(v[r]);
+        }
       }
       if (keep_pre && (epi & MM_EPI_RESIDUAL)) {
 #pragma unroll
@@ -607,7 +609,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   int tile = blockIdx.x;
   int pm = 0, pn = 0;
   if (tile < total_full) block_to_tile(tile, g.nbm, g.nbn, pm, pn);
-  // EK (epilogue kind) is a TEMPLATE parameter: 0 plain, 2 SwiGLU backward (mm_gemm_swiglu_bwd, NN), 3 fused gate|up
+  // EK (epilogue kind) is a TEMPLATE parameter: 0 plain without activation code, 1 plain with the GELU kinds (NT: a forward
+  // Linear with an activation), 2 SwiGLU backward (mm_gemm_swiglu_bwd, NN), 3 fused gate|up
   // (mm_gemm_swiglu_fwd, NT 256x256).  With the rare epilogues inlined behind runtime branches every GEMM of the step ran
   // 1.6 % slower than the round-1 library on the same box (tools/gemm_bench.py, 15 shapes); with them in their own
   // instantiations the plain kernel is the round-1 kernel again.
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
     }
     if constexpr (EK == 3) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
     else if constexpr (EK == 2) gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
-    else gemm_epilogue_plain<MREP, NREP, (BM_ * BN_ <= 128 * 128)>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    else gemm_epilogue_plain<MREP, NREP, (BM_ * BN_ <= 128 * 128) && EK == 1, EK == 1>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     tile = next;
     m0 = nm0;
     n0 = nn0;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
         }
       }
       if constexpr (EK == 2) gemm_epilogue_swiglu_bwd<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
-      else gemm_epilogue_plain<MREP, NREPH, false>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
+      else gemm_epilogue_plain<MREP, NREPH, false, EK == 1>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
     }
   }
 }
@@ -1201,6 +1204,9 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       } else if (epilogue & MM_EPI_SWIGLU_BWD) {                          // mm_gemm_swiglu_bwd: NN
         if (layout != MM_GEMM_NN) return MM_ERR_ARG;
         MM_LAUNCH_DMA(true, false, 2);
+      } else if (epilogue & (MM_EPI_GELU_ERF | MM_EPI_QUICK_GELU | MM_EPI_GELU_TANH)) {      // activation: NT (mm_gemm / mm_gemm_act_fwd)
+        if (layout != MM_GEMM_NT) return MM_ERR_UNSUPPORTED;
+        MM_LAUNCH_DMA(true, true, 1);
       } else {
         switch (layout) {
           case MM_GEMM_NT: MM_LAUNCH_DMA(true, true, 0); break;
