@@ -44,7 +44,9 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
         remarks = [ln for ln in r.stderr.splitlines() if "remark:" in ln]
-        other = [ln for ln in r.stderr.splitlines() if "remark:" not in ln and "-Rpass-analysis" not in ln]
+        import re
+        ctx = re.compile(r"^\s*\d*\s*\|")               # the source excerpt clang prints under each remark
+        other = [ln for ln in r.stderr.splitlines() if "remark:" not in ln and "-Rpass-analysis" not in ln and not ctx.match(ln)]
         if other:
             sys.stderr.write("\n".join(other) + "\n")
         if r.returncode != 0:
