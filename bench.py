@@ -143,13 +143,12 @@ def measure_gemm_roofline(trainer, batch):
 
 
 def kernel_source_sha():
-    """sha256 over the sources of the kernel `roofline` describes (the GEMM: csrc/mm_gemm.hip, csrc/mm_common.h, the ABI header):
-    identifies the code a PMC pass was taken on (.git does not travel to the GPU box, so a commit id cannot be checked there).
-    A change to that kernel voids the recorded traffic; a change to an unrelated kernel does not."""
+    """sha256 over the sources of the kernel `roofline` describes (the GEMM: csrc/mm_gemm.hip and csrc/mm_common.h): identifies
+    the code a PMC pass was taken on (.git does not travel to the GPU box, so a commit id cannot be checked there).  A change to
+    that kernel voids the recorded traffic; a change to an unrelated kernel or a new entry point in the ABI header does not."""
     import hashlib
     h = hashlib.sha256()
-    for fn in (os.path.join(ROOT, "multimeditron_amd", "csrc", "mm_gemm.hip"), os.path.join(ROOT, "multimeditron_amd", "csrc", "mm_common.h"),
-               os.path.join(ROOT, "include", "mm_hip.h")):
+    for fn in (os.path.join(ROOT, "multimeditron_amd", "csrc", "mm_gemm.hip"), os.path.join(ROOT, "multimeditron_amd", "csrc", "mm_common.h")):
         h.update(open(fn, "rb").read())
     return h.hexdigest()[:16]
 
