@@ -261,6 +261,20 @@ int mm_comm_reduce_scatter(void* comm, int dtype, void* buf, int64_t count, void
 int mm_comm_all_gather(void* comm, int dtype, void* buf, int64_t count, void* stream);
 int mm_comm_finalize(void* comm);
 
+/* ---- image preprocessing on the device (optional row) ---------------------------------------------------
+ * Replaces the CPU image processor the reference runs in its collator (image_modality.py:77,88-93 -> HF CLIPImageProcessor:
+ * PIL resize BICUBIC, center crop, rescale 1/255, normalize) for an already decoded uint8 RGB image [src_h, src_w, 3] in HBM.
+ * Pillow's two-pass fixed-point resampling, bit for bit; the int32 weight tables (bounds [n][2] = first tap, tap count; coef
+ * [n][k]) are made on the host exactly as Pillow's precompute_coeffs / normalize_coeffs_8bpc do (dataset/gpu_image.py).
+ * mm_image_resample_h: tmp [nrows, cw, 3] uint8 = horizontal pass of source rows r0 .. r0+nrows-1, resized columns left ..
+ * left+cw-1.  mm_image_resample_v_norm: out [3, ch, cw] fp32 = vertical pass of resized rows top .. top+ch-1 over tmp, then
+ * x * rescale, (x - mean) / std as separate float32 operations (the CPU path's); mean / std are HOST arrays of 3 floats.   */
+int mm_image_resample_h(const void* src_u8, int src_h, int src_w, int src_row_stride, int r0, int nrows, const int* xbounds,
+                        const int* xcoef, int kx, int left, int cw, void* tmp_u8, void* stream);
+int mm_image_resample_v_norm(const void* tmp_u8, int r0, int nrows, int cw, const int* ybounds, const int* ycoef, int ky, int top,
+                             int ch, float rescale, int do_rescale, const float* mean3_host, const float* std3_host, int do_norm,
+                             float* out_chw, void* stream);
+
 /* ---- utilities ---------------------------------------------------------------------------------------------------- */
 int mm_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int64_t n, void* stream);
 int mm_fill_zero(void* p, int64_t bytes, void* stream);

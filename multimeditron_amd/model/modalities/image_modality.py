@@ -17,11 +17,15 @@ from .base import AutoModality, BaseModality, BaseModalityConfig, BaseModalityPr
 
 class ImageConfig(BaseModalityConfig):
     def __init__(self, hidden_size: int = 4096, clip_name: str = "openai/clip-vit-large-patch14",
-                 projection_type: str = "mlp", use_2d_position_ids: bool = False, **kwargs):
+                 projection_type: str = "mlp", use_2d_position_ids: bool = False, gpu_preprocess: bool = False, **kwargs):
+        """reference image_modality.py:14-44, plus `gpu_preprocess` (not in the reference): the processor then hands the decoded
+        uint8 RGB image through the collator and `DevicePrefetcher(image_preprocessors=...)` resizes / crops / normalises it on the
+        device (dataset/gpu_image.py: bit-identical pixels)."""
         super().__init__(modality_type="image", hidden_size=hidden_size)
         self.clip_name = clip_name
         self.projection_type = projection_type
         self.use_2d_position_ids = use_2d_position_ids
+        self.gpu_preprocess = gpu_preprocess
 
 
 class ClipImagePreprocessor:
@@ -71,13 +75,19 @@ class ImageProcessor(BaseModalityProcessor):
         super().__init__(config)
         assert config.clip_name is not None, "clip_name must be specified in the config"
         vis = VisionConfig.from_dict(resolve_vision_config(config.clip_name))
-        self.image_processor = ClipImagePreprocessor(resolve_preprocessor_config(config.clip_name, vis.image_size))
+        self.preprocessor_config = resolve_preprocessor_config(config.clip_name, vis.image_size)
+        self.image_processor = ClipImagePreprocessor(self.preprocessor_config)
+        self.gpu_preprocess = bool(getattr(config, "gpu_preprocess", False))
         self._image_size = vis.image_size // vis.patch_size
         self._num_patches_per_entry = self._image_size ** 2
 
     def process(self, modality: Dict[str, Any]) -> Dict[str, Any]:
         out = modality.copy()
-        out[MODALITY_VALUE_KEY] = self.image_processor(modality[MODALITY_VALUE_KEY])
+        if self.gpu_preprocess:            # decoded RGB bytes only: the rest happens on the device (train/prefetch.py)
+            from ...dataset.gpu_image import GpuClipPreprocessor
+            out[MODALITY_VALUE_KEY] = GpuClipPreprocessor.to_rgb_uint8(modality[MODALITY_VALUE_KEY])
+        else:
+            out[MODALITY_VALUE_KEY] = self.image_processor(modality[MODALITY_VALUE_KEY])
         out[NUM_EMBEDDINGS_KEY] = self._num_patches_per_entry
         if self.config.use_2d_position_ids:
             g = torch.arange(self._image_size, dtype=torch.long)

@@ -41,12 +41,15 @@ class _Slot:
 
 
 class DevicePrefetcher:
-    def __init__(self, batches: Iterable[Dict[str, Any]], device=None, depth: int = 2):
+    def __init__(self, batches: Iterable[Dict[str, Any]], device=None, depth: int = 2, image_preprocessors: Optional[Dict[str, Any]] = None):
+        """image_preprocessors: {modality type: GpuClipPreprocessor} for modalities whose processor runs with `gpu_preprocess`
+        (their `stacked` values are decoded uint8 RGB arrays): resize / crop / normalise then run HERE, on the staging stream."""
         if not torch.cuda.is_available():
             raise RuntimeError("DevicePrefetcher stages batches into HBM: it needs a GPU (no CPU fallback)")
-        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(device=self.device)
         self.slots: List[_Slot] = [_Slot() for _ in range(max(2, depth))]
+        self.image_preprocessors = dict(image_preprocessors or {})
         self._it: Iterator = iter(batches)
         self._queue: List[_Slot] = []
         self._next_slot = 0
@@ -83,7 +86,14 @@ class DevicePrefetcher:
                     for t, v in (pm.get(name) or {}).items():
                         dpm[name][t] = self._h2d(slot, f"{name}.{t}", v)
                 for t, vals in (pm.get("stacked") or {}).items():
-                    if torch.is_tensor(vals):
+                    import numpy as np
+                    if not torch.is_tensor(vals) and len(vals) and all(isinstance(x, np.ndarray) and x.dtype == np.uint8 for x in vals):
+                        pp = self.image_preprocessors.get(t)
+                        if pp is None:
+                            raise ValueError(f"modality '{t}' delivers raw uint8 images (gpu_preprocess) but DevicePrefetcher has no "
+                                             f"image_preprocessors['{t}']")
+                        dpm["stacked"][t] = pp(vals)                   # device-side resize / crop / normalise on this stream
+                    elif torch.is_tensor(vals):
                         dpm["stacked"][t] = self._h2d(slot, f"stacked.{t}", vals)
                     elif len(vals) and all(torch.is_tensor(x) and x.shape == vals[0].shape and not x.is_cuda for x in vals):
                         p = slot.buf(f"stacked.{t}", (len(vals),) + tuple(vals[0].shape), vals[0].dtype)

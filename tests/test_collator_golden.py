@@ -15,13 +15,10 @@ from multimeditron_amd.model.model import ChatTemplate
 from multimeditron_amd.model.modalities import AutoModality, ImageConfig
 
 
-@pytest.fixture(scope="module")
-def env(golden_dir, tmp_path_factory):
-    pytest.importorskip("transformers")
+def _tokenizer_factory(meta):
+    """side -> the synthetic whitespace WordLevel tokenizer of the fixture (tools/make_golden.py make_tokenizer)."""
     from tokenizers import Tokenizer, models, pre_tokenizers
     from transformers import PreTrainedTokenizerFast
-    meta = json.load(open(os.path.join(golden_dir, "collator.meta.json")))
-    vec = load_file(os.path.join(golden_dir, "collator.vectors.safetensors"))
 
     def make_tok(side):
         vocab = {w: i for i, w in enumerate(meta["words"])}
@@ -35,15 +32,30 @@ def env(golden_dir, tmp_path_factory):
         t.padding_side = side
         return t
 
+    return make_tok
+
+
+def _spaced_llama_template():
+    ct = ChatTemplate.llama()
+    for role in ct.delimiters:   # the synthetic whitespace tokenizer needs spaced role tags (as in make_golden.py)
+        ct.delimiters[role] = {"start": f"<|start_header_id|> {role} <|end_header_id|>", "end": "<|eot_id|>"}
+    return ct
+
+
+@pytest.fixture(scope="module")
+def env(golden_dir, tmp_path_factory):
+    pytest.importorskip("transformers")
+    meta = json.load(open(os.path.join(golden_dir, "collator.meta.json")))
+    vec = load_file(os.path.join(golden_dir, "collator.vectors.safetensors"))
+    make_tok = _tokenizer_factory(meta)
+
     d = tmp_path_factory.mktemp("clip")
     json.dump({"vision_config": {"hidden_size": 128, "intermediate_size": 256, "num_hidden_layers": 2, "num_attention_heads": 2,
                                  "image_size": meta["image_size"], "patch_size": meta["patch_size"]}}, open(d / "config.json", "w"))
     json.dump({"size": {"shortest_edge": meta["image_size"]}, "crop_size": {"height": meta["image_size"], "width": meta["image_size"]}},
               open(d / "preprocessor_config.json", "w"))
     proc = AutoModality.preprocessor_from_name("meditron_clip", ImageConfig(hidden_size=128, clip_name=str(d)))
-    ct = ChatTemplate.llama()
-    for role in ct.delimiters:   # the synthetic whitespace tokenizer needs spaced role tags (as in make_golden.py)
-        ct.delimiters[role] = {"start": f"<|start_header_id|> {role} <|end_header_id|>", "end": "<|eot_id|>"}
+    ct = _spaced_llama_template()
     return meta, vec, make_tok, proc, ct, os.path.join(golden_dir, "mock_dataset")
 
 

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; defs=$2
 mkdir -p build_diag/obj_$name
 objs=""
-for f in mm_gemm mm_attn mm_rowwise mm_embed mm_optim mm_debug mm_comm; do
+for f in mm_gemm mm_attn mm_rowwise mm_embed mm_optim mm_debug mm_comm mm_image; do
   o=multimeditron_amd/csrc/build/$f.o
   if [ $f = mm_gemm ] || [ $f = mm_attn ]; then
     o=build_diag/obj_$name/$f.o
