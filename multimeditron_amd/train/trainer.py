@@ -84,10 +84,10 @@ class MultimodalTrainer:
         """Hold back the weight-gradient GEMMs of the first decoder layers (the last to run in backward) and launch them on a
         side stream beside the modality backward (functional.set_wgrad_deferral).  Only when a modality embedder is
         trainable (FULL mode): otherwise there is nothing latency-bound at the tail to hide them under.  Measured on the 8B
-        workload at 1 GPU: 12-16 layers -1.2 % step time (the modality chain also slows down when it shares the chip, so most
+        workload at 1 GPU (round 2, tools/step_ab.py): 0 / 8 / 12 / 16 / 20 layers = 391.7 / 391.4 / 388.9 / 386.1 / 386.8 ms/step (the modality chain also slows down when it shares the chip, so most
         of its 14 ms stays exposed); 2-8 layers: no change.  Off under data parallelism: a held-back gradient cannot
         enter its all-reduce bucket before the end of backward.  MM_DEFER_WGRAD_LAYERS overrides the layer count (0 = off)."""
-        n = int(os.environ.get("MM_DEFER_WGRAD_LAYERS", "12" if self.world == 1 else "0"))
+        n = int(os.environ.get("MM_DEFER_WGRAD_LAYERS", "16" if self.world == 1 else "0"))
         tail = any(p.requires_grad for mod in self.model.modalities_with_projection for p in mod.feature_extractor.parameters()) \
             if hasattr(self.model, "modalities_with_projection") else False
         layers = getattr(getattr(self.model.model, "model", None), "layers", None)
