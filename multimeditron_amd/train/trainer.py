@@ -109,10 +109,11 @@ class MultimodalTrainer:
         DEFAULT: one sweep (`sumsq_kernel`, 5.4 TB/s = 3.1 ms) over the trainable ranges after backward, partials summed in a
         fixed order by the finish kernel.  Two ways to hide those 3 ms were built, measured on the 8B step with
         tools/step_ab.py (same box, same process, interleaved) and found to COST time; they stay behind switches:
-          * MM_FUSED_NORM=1 -- the decoder's weight-gradient GEMMs (97 % of the parameters) and an untied lm_head leave the
-            sum of squares of what they store in per-wave slots (`mm_gemm_sumsq`: no atomics, bit-reproducible) and only the
-            rest is swept: 399.6 vs 395.5 ms/step.  The epilogue's extra convert + FMA per stored element (512 VALU
-            instructions per lane and 256x256 tile) lengthens every wgrad GEMM by more than the sweep it replaces.
+          * MM_FUSED_NORM=1 -- the decoder's weight-gradient GEMMs (97 % of the parameters) and an untied lm_head report the sum of
+            squares of what they store (`mm_gemm_sumsq`, per-workgroup slots: no atomics, bit-reproducible) and only the rest is
+            swept: 399.6 vs 395.5 ms/step when the sum was taken inside the GEMM epilogue (an extra convert + FMA per stored
+            element lengthened every wgrad GEMM by more than the sweep it replaced, and the inlined path cost every other GEMM
+            1.6 %: csrc/mm_gemm.hip).  `mm_gemm_sumsq` is now the GEMM followed by a reduction pass over its output.
           * MM_EARLY_NORM=1 -- each decoder layer swept on a side stream as soon as its wgrads are enqueued, under the rest
             of backward: 409.2 vs 404.8 ms/step: the sweep's HBM reads slow the GEMMs they run beside.
         One GPU only in both cases: under data parallelism a gradient is final only after its bucket's all-reduce."""
