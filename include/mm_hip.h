@@ -236,6 +236,30 @@ int mm_decode_select(const int64_t* tok, unsigned char* finished, int64_t eos, i
 int mm_expert_fuse(int dtype, int backward, int mode, const void* X, const float* gate, const int* idx, int J, int E, int n,
                    int64_t L, void* out, void* stream);
 
+/* ---- MoE image modality: the core of `CrossAttention` (model/attention.py:79-96: softmax(q k^T * scale) -> attn_drop -> @ v,
+ * called with the generalist's P tokens as queries over the specialists' (E-1)*P tokens, image_modality_moe.py:177-203 and
+ * image_modality_moe_pep.py:216-244) for head widths the flash kernels do not tile: any D that is a multiple of 8 up to 512
+ * (MM_BF16; the shipped recipes need 96 = 768/8 and 512 = 4096/8), any D for MM_F32; Nkv <= 512 (the whole score row of a
+ * query stays in registers: no online softmax).  q [n,Nq,H,D], k/v [n,Nkv,H,D] with element strides (image, token, head);
+ * out [n,Nq,H,D] contiguous; lse [n,H,Nq] f32.  drop_p = probability of zeroing an attention weight (`attn_drop`, 0.1 in the
+ * reference whenever the module trains; 0 = eval): Philox4x32-10 with key `seed` and counter (call, offset); weight (row, key)
+ * with row = (image * H + head) * Nq + query takes component key & 3 of call row * KP/4 + key/4, KP = Nkv rounded up to 32
+ * (mm_dropout_mask(seed, offset, rows * KP, p) lists the same keep flags).  Backward regenerates the mask, is deterministic
+ * (no atomics) and needs a workspace of mm_xattn_ws_bytes; dq/dk/dv take the strides of q/k/v.                            */
+int mm_xattn_ws_bytes(int dtype, int n, int Nq, int Nkv, int H, int64_t* bytes);
+int mm_xattn_fwd(int dtype, const void* q, const void* k, const void* v, int n, int Nq, int Nkv, int H, int D, int64_t q_sb,
+                 int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh,
+                 float scale, float drop_p, int64_t seed, int64_t offset, void* out, float* lse, void* stream);
+int mm_xattn_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                 int n, int Nq, int Nkv, int H, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
+                 int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, float scale, float drop_p, int64_t seed, int64_t offset,
+                 void* dq, void* dk, void* dv, void* ws, int64_t ws_bytes, void* stream);
+/* y[i] = keep(i) ? x[i] / (1 - p) : 0 -- nn.Dropout of CrossAttention's output projection (attention.py:41,98, `proj_drop`);
+ * element i takes component i & 3 of Philox call i / 4.  Its backward is the same call on dy with the same (seed, offset).
+ * mm_dropout_mask: the keep flags (uint8 0/1) of elements 0 .. n-1 of that stream (tests).                                */
+int mm_dropout(int dtype, const void* x, int64_t n, float p, int64_t seed, int64_t offset, void* y, void* stream);
+int mm_dropout_mask(int64_t seed, int64_t offset, int64_t n, float p, void* mask_u8, void* stream);
+
 /* ---- optimizer: AdamW (config_alignment.yaml:38-59 -> torch.optim.AdamW semantics) + grad-norm clip ----------------
  * sumsq partial: out[blk] = sum g^2 over a slice; mm_gradnorm_finish: total[0] = sqrt(sum) ; clip coef in total[1]  */
 int mm_gradnorm_partial(int dtype, const void* g, int64_t n, float* partial, int nblk, void* stream);

@@ -46,6 +46,7 @@ struct GemmArgs {
   int swi_I;
   void* C2; int ldc2;
   const void* aux; int ldaux;   // MM_EPI_SWIGLU_BWD: the saved pre-activations [M, 2I]
+  int pipe;                     // pipelined epilogue (mm_set_option "gemm_epi_pipe", default 1)
 };
 constexpr int MM_EPI_SWIGLU_BWD = 1 << 20;   // internal epilogue flag (mm_gemm_swiglu_bwd), not part of the ABI enum
 
@@ -280,6 +281,186 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x
       *(bf16x4*)(dp + g.N) = du;
     }
   }
+}
+
+// ---- the same two epilogues, PIPELINED (round 3) -------------------------------------------------------------------------
+// The loops above compile to 32 serial round trips per wave and tile: every (i, j) step is `branch on the bounds -> load
+// residual / C / aux -> s_waitcnt vmcnt(0) (which also waits for the PREVIOUS step's stores) -> arithmetic -> store`, because the
+// bounds `continue`s are divergent branches the loads cannot be hoisted across.  With K = 4096 (64 K-steps of ~1.1 us) that tail
+// was a fifth of the tile: the SwiGLU-backward dgrad ran at 1017 TFLOP/s inside the step where the plain dgrad GEMMs reach 1346
+// (profiles/r03_*).  Here the bounds go into the buffer instructions' hardware range check (descriptor anchored at the wave's
+// first row, so a row >= M lies beyond num_records; a column group >= N gets an out-of-range offset), nothing branches per
+// element, and the operands of row block i + 1 are requested before row block i is computed and stored.  Same arithmetic, same
+// rounding points: bit-identical output.  A wave whose columns reach a ragged N (N % 4 != 0: the padded-stride logits)
+// keeps the scalar path.
+constexpr unsigned EPI_OOB = 0xFFFFFFFFu;
+
+template <int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+  const int l = threadIdx.x & 63;
+  mw = __builtin_amdgcn_readfirstlane(mw);
+  nw = __builtin_amdgcn_readfirstlane(nw);
+  const int epi = g.epi;
+  const bool has_res = (epi & MM_EPI_RESIDUAL) != 0, has_acc = (epi & MM_EPI_ACCUMULATE) != 0, has_bias = (epi & MM_EPI_BIAS) != 0;
+  const int rows = g.M - mw;                                   // <= 0: the whole wave tile is below the matrix (everything out of range)
+  auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)rows * g.ldc * 2);
+  auto rr = make_rsrc(has_res ? (const bf16*)g.residual + (int64_t)mw * g.ldr : (const bf16*)g.C, has_res ? (int64_t)rows * g.ldr * 2 : 0);
+  unsigned colb[NREP];                                         // byte offset of the lane's 4 columns inside a row, or out of range
+  float bv[NREP][4];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int n = nw + j * 16 + 4 * (l >> 4);
+    colb[j] = n + 3 < g.N ? (unsigned)n * 2u : EPI_OOB;          // a group that straddles a ragged N: scalar tail below
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+    if (has_bias && n + 3 < g.N) {
+      const bf16x4 b4 = *(const bf16x4*)((const bf16*)g.bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = (float)b4[r];
+    }
+  }
+  u32x2 rbuf[2][NREP], cbuf[2][NREP];
+  auto request = [&](int i, int s) {
+    const unsigned rowc = (unsigned)((i * 16 + (l & 15)) * g.ldc) * 2u, rowr = (unsigned)((i * 16 + (l & 15)) * g.ldr) * 2u;
+    if (has_res) {
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) rbuf[s][j] = __builtin_amdgcn_raw_buffer_load_b64(rr, colb[j] == EPI_OOB ? EPI_OOB : rowr + colb[j], 0, 0);
+    }
+    if (has_acc) {
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) cbuf[s][j] = __builtin_amdgcn_raw_buffer_load_b64(rc, colb[j] == EPI_OOB ? EPI_OOB : rowc + colb[j], 0, 0);
+    }
+  };
+  request(0, 0);
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    if (i + 1 < MREP) request(i + 1, (i + 1) & 1);
+    const unsigned rowc = (unsigned)((i * 16 + (l & 15)) * g.ldc) * 2u;
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (has_bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
+      }
+      if (has_res) {
+        const bf16x4 rv = __builtin_bit_cast(bf16x4, rbuf[i & 1][j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+      if (has_acc) {
+        const bf16x4 cv = __builtin_bit_cast(bf16x4, cbuf[i & 1][j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)cv[r];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rc, colb[j] == EPI_OOB ? EPI_OOB : rowc + colb[j], 0, 0);
+    }
+  }
+  // ragged N (N % 4 != 0: the padded-stride logits): the one column group that straddles N, element by element
+  if ((g.N & 3) != 0 && nw + NREP * 16 > (g.N & ~3)) {
+    const bf16* bias = (const bf16*)g.bias;
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+      const int m = mw + i * 16 + (l & 15);
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) {
+        const int n = nw + j * 16 + 4 * (l >> 4);
+        if (m < g.M && n < g.N && n + 3 >= g.N) {
+          bf16* cp = (bf16*)g.C + (int64_t)m * g.ldc + n;
+          for (int r = 0; r < 4; ++r)
+            if (n + r < g.N) {
+              float v = acc[i][j][r];
+              if (has_bias) v += (float)bias[n + r];
+              if (has_res) v += (float)((const bf16*)g.residual)[(int64_t)m * g.ldr + n + r];
+              if (has_acc) v += (float)cp[r];
+              cp[r] = (bf16)v;
+            }
+        }
+      }
+    }
+  }
+}
+
+template <int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue_swiglu_bwd_pipe(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+  const int l = threadIdx.x & 63;
+  mw = __builtin_amdgcn_readfirstlane(mw);
+  nw = __builtin_amdgcn_readfirstlane(nw);
+  const int rows = g.M - mw;
+  auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)rows * g.ldc * 2);
+  auto ra = make_rsrc((const bf16*)g.aux + (int64_t)mw * g.ldaux, (int64_t)rows * g.ldaux * 2);
+  unsigned colb[NREP];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int n = nw + j * 16 + 4 * (l >> 4);
+    colb[j] = n < g.N ? (unsigned)n * 2u : EPI_OOB;         // N % 4 == 0 (checked by the host): a column group is whole or absent
+  }
+  const unsigned upo = (unsigned)g.N * 2u;                   // the up half sits N columns to the right of the gate half
+  u32x2 gbuf[2][NREP], ubuf[2][NREP];
+  auto request = [&](int i, int s) {
+    const unsigned rowa = (unsigned)((i * 16 + (l & 15)) * g.ldaux) * 2u;
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const unsigned o = colb[j] == EPI_OOB ? EPI_OOB : rowa + colb[j];
+      gbuf[s][j] = __builtin_amdgcn_raw_buffer_load_b64(ra, o, 0, 0);
+      ubuf[s][j] = __builtin_amdgcn_raw_buffer_load_b64(ra, o == EPI_OOB ? EPI_OOB : o + upo, 0, 0);
+    }
+  };
+  request(0, 0);
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    if (i + 1 < MREP) request(i + 1, (i + 1) & 1);
+    const unsigned rowc = (unsigned)((i * 16 + (l & 15)) * g.ldc) * 2u;
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      const bf16x4 gv = __builtin_bit_cast(bf16x4, gbuf[i & 1][j]), uv = __builtin_bit_cast(bf16x4, ubuf[i & 1][j]);
+      bf16x4 dg, du;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gf = (float)gv[r], sig = 1.0f / (1.0f + __expf(-gf));
+        const float sg = gf * sig;
+        const float dd = (float)(bf16)acc[i][j][r];
+        du[r] = (bf16)(dd * sg);
+        dg[r] = (bf16)(dd * (float)uv[r] * (sig * (1.0f + gf * (1.0f - sig))));
+      }
+      const unsigned o = colb[j] == EPI_OOB ? EPI_OOB : rowc + colb[j];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dg), rc, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, du), rc, o == EPI_OOB ? EPI_OOB : o + upo, 0, 0);
+    }
+  }
+}
+
+#ifndef MM_GEMM_EPI_PIPE
+#define MM_GEMM_EPI_PIPE 1
+#endif
+
+// EK == 0 / EK == 2 epilogue of the LDS-DMA kernels.  The pipelined forms address a wave tile with 32-bit byte offsets: the host
+// (gemm_launch) sends a problem whose leading dimensions do not allow that to the register-staged kernel.
+template <int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue_ek0(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+#if MM_GEMM_EPI_PIPE == 2                 // A/B build: both epilogues compiled in, chosen by mm_set_option("gemm_epi_pipe")
+  if (!g.pipe) { gemm_epilogue_plain<MREP, NREP, false, false>(g, acc, mw, nw); return; }
+#endif
+#if MM_GEMM_EPI_PIPE
+  gemm_epilogue_plain_pipe<MREP, NREP>(g, acc, mw, nw);
+#else
+  gemm_epilogue_plain<MREP, NREP, false, false>(g, acc, mw, nw);
+#endif
+}
+
+template <int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue_ek2(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+#if MM_GEMM_EPI_PIPE == 2
+  if (!g.pipe) { gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, mw, nw); return; }
+#endif
+#if MM_GEMM_EPI_PIPE
+  gemm_epilogue_swiglu_bwd_pipe<MREP, NREP>(g, acc, mw, nw);
+#else
+  gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, mw, nw);
+#endif
 }
 
 // runtime dispatch between the two (the register-staged 128x128 kernel, which the step does not run; the LDS-DMA kernels pick
@@ -709,7 +890,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
       }
     }
     if constexpr (EK == 3) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
-    else if constexpr (EK == 2) gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    else if constexpr (EK == 2) gemm_epilogue_ek2<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    else if constexpr (EK == 0) gemm_epilogue_ek0<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     else gemm_epilogue_plain<MREP, NREP, (BM_ * BN_ <= 128 * 128) && EK == 1, EK == 1>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     tile = next;
     m0 = nm0;
@@ -781,7 +963,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if constexpr (EK == 2) gemm_epilogue_swiglu_bwd<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
+      if constexpr (EK == 2) gemm_epilogue_ek2<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
+      else if constexpr (EK == 0) gemm_epilogue_ek0<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
       else gemm_epilogue_plain<MREP, NREPH, false, EK == 1>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
     }
   }
@@ -1001,6 +1184,7 @@ static int small_variant(int M, int N, int K) {
   const int64_t t = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
   return t <= 96 ? 4 : (t <= 320 ? 3 : 0);
 }
+static int g_opt_epi_pipe = 1;      // pipelined, branch-free epilogue of the plain / SwiGLU-backward LDS-DMA kernels
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
 
 extern "C" int mm_attn_set_issue_waves(int v);
@@ -1017,6 +1201,7 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_skinny")) { g_opt_skinny = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_small")) { if (value < -1 || value > 5) return MM_ERR_ARG; g_opt_small = value; return MM_OK; }
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_epi_pipe")) { g_opt_epi_pipe = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 6) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
   return MM_ERR_ARG;
@@ -1028,6 +1213,7 @@ extern "C" int mm_get_option(const char* name, int* value) {
   if (!strcmp(name, "gemm_skinny")) { *value = g_opt_skinny; return MM_OK; }
   if (!strcmp(name, "gemm_small")) { *value = g_opt_small; return MM_OK; }
   if (!strcmp(name, "gemm_persist")) { *value = g_opt_persist; return MM_OK; }
+  if (!strcmp(name, "gemm_epi_pipe")) { *value = g_opt_epi_pipe; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { *value = g_opt_issue_waves; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { *value = g_opt_kernel; return MM_OK; }
   return MM_ERR_ARG;
@@ -1126,6 +1312,7 @@ extern "C" int mm_gemm_sumsq(int dtype, int layout, int M, int N, int K, const v
 }
 
 static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
+  g.pipe = g_opt_epi_pipe;
   const int M = g.M, N = g.N, K = g.K, lda = g.lda, ldb = g.ldb, ldc = g.ldc, ldr = g.ldr, epilogue = g.epi;
   const void *A = g.A, *B = g.B;
   void* C = g.C;
@@ -1147,7 +1334,10 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       return MM_OK;
     }
     // the DMA kernels address a K-strided operand with 32-bit byte offsets over the whole matrix
-    const bool fits32 = (layout == MM_GEMM_NT) || ((int64_t)K * ldb * 2 < 0xFFFFFFFFll && (layout != MM_GEMM_TN || (int64_t)K * lda * 2 < 0xFFFFFFFFll));
+    // ... and (pipelined epilogues) one wave tile of C / residual / aux with 32-bit byte offsets: 128 rows of the largest leading dimension
+    const int64_t ldmax = (int64_t)ldc > ldr ? (ldc > g.ldaux ? ldc : g.ldaux) : (ldr > g.ldaux ? ldr : g.ldaux);
+    const bool fits32 = ldmax * 128 * 2 + (int64_t)N * 2 < 0x7FFFFFFFll &&
+                        ((layout == MM_GEMM_NT) || ((int64_t)K * ldb * 2 < 0xFFFFFFFFll && (layout != MM_GEMM_TN || (int64_t)K * lda * 2 < 0xFFFFFFFFll)));
     const int64_t tiles_128 = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
     const int64_t tiles_256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     int variant = 0;   // 0 = v1 (128x128 register staged); DMA tiles: 1 = 256x128, 2 = 256x256, 3 = 128x128, 4 = 64x128, 5 = 64x64

@@ -51,18 +51,61 @@ def _ready(p):
 _defer = None
 
 
-def set_wgrad_deferral(stream, params):
-    """stream: side HIP stream for the deferred GEMMs; params: the first Parameter of every deferred group (held weakly).
-    stream=None disables."""
+def set_wgrad_deferral(stream, params, immediate=()):
+    """stream: side HIP stream for the deferred GEMMs; params: the first Parameter of every deferred group (held weakly);
+    immediate: first Parameters of groups whose wgrad GEMM is not held back but launched AT ONCE on the side stream (it then
+    runs beside the input-gradient chain of the main stream instead of in front of it).  stream=None disables."""
     import weakref
     global _defer
     _defer = None if stream is None else {"stream": stream, "params": {id(p): weakref.ref(p) for p in params}, "items": [],
-                                          "event": None}
+                                          "event": None, "now": {id(p): weakref.ref(p) for p in immediate}}
 
 
 def _is_deferred(p):
     r = _defer["params"].get(id(p)) if _defer is not None else None
     return r is not None and r() is p        # the weak reference guards against id() reuse by a later model
+
+
+def _wgrad_on_side(dy, x, wg):
+    """Launch one wgrad GEMM on the side stream now, ordered after everything the main stream has been given so far."""
+    from ._lib import get_option, lib
+    d = _defer
+    main, side = torch.cuda.current_stream(), d["stream"]
+    ev0 = torch.cuda.Event()
+    ev0.record(main)
+    side.wait_event(ev0)
+    persist = get_option("gemm_persist")
+    lib().mm_set_option(b"gemm_persist", 0)          # one tile per workgroup: fills the CUs the main stream's tails leave
+    try:
+        with torch.cuda.stream(side):
+            dy.record_stream(side)
+            x.record_stream(side)
+            g, acc = wg.grad_target()
+            K.linear_wgrad(dy, x, g, acc, sumsq=wg.sumsq_slots())
+            wg.ready()
+            ev = torch.cuda.Event()
+            ev.record(side)
+    finally:
+        lib().mm_set_option(b"gemm_persist", persist)
+    d["event"] = ev
+
+
+def _wgrad(dy, x, wg):
+    """The weight-gradient GEMM of one parameter group: now on this stream, now on the side stream, or held back."""
+    if not wg.requires_grad:
+        return
+    if _defer is not None:
+        key = id(wg.params[0])
+        r = _defer["now"].get(key)
+        if r is not None and r() is wg.params[0]:
+            _wgrad_on_side(dy, x, wg)
+            return
+        if _is_deferred(wg.params[0]):
+            _defer["items"].append((dy, x, wg))
+            return
+    g, acc = wg.grad_target()
+    K.linear_wgrad(dy, x, g, acc, sumsq=wg.sumsq_slots())
+    wg.ready()
 
 
 def flush_deferred_wgrads():
@@ -192,13 +235,7 @@ class LinearFn(torch.autograd.Function):
             g, acc = bg.grad_target()
             K.colsum(dy, g, acc)
             bg.ready()
-        if wg.requires_grad:
-            if _is_deferred(wg.params[0]):
-                _defer["items"].append((dy, x, wg))
-            else:
-                g, acc = wg.grad_target()
-                K.linear_wgrad(dy, x, g, acc, sumsq=wg.sumsq_slots())
-                wg.ready()
+        _wgrad(dy, x, wg)
         dx = K.linear_dgrad(dy, wg.tensor()) if ctx.needs_input_grad[0] else None
         return dx, dres, None, None, None, None, None
 
@@ -342,36 +379,79 @@ def attention_head_width(d: int, dtype) -> int:
     return 64 if d < 64 else 128
 
 
+# Philox streams of the dropout kernels: key = torch's seed (torch.manual_seed governs it), one counter offset per dropout site
+# and call; backward regenerates a mask from the (seed, offset) its forward drew.
+_dropout_calls = 0
+
+
+def next_dropout_stream():
+    global _dropout_calls
+    _dropout_calls += 1
+    return int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF, _dropout_calls
+
+
 class CrossAttentionFn(torch.autograd.Function):
     """Non-causal attention of Nq queries over Nkv keys/values with separate inputs (model/attention.py:79-96 between the
-    projections): q2d [n*Nq, h*d], kv2d [n*Nkv, 2*h*d] (k | v, one fused projection output) -> [n*Nq, h*d]."""
+    projections): q2d [n*Nq, h*d], kv2d [n*Nkv, 2*h*d] (k | v, one fused projection output) -> [n*Nq, h*d].
+    drop_p > 0: dropout on the attention probabilities (attention.py:40,91).  Up to 512 keys the one-pass kernel mm_xattn_* runs
+    (any head width up to 512: the reference's recipes use 96 and 512); beyond that the flash kernels (d in {64, 128}, no dropout)."""
 
     @staticmethod
-    def forward(ctx, q2d, kv2d, n, Nq, Nkv, heads, d, scale):
+    def forward(ctx, q2d, kv2d, n, Nq, Nkv, heads, d, scale, drop_p):
         C = heads * d
         q = q2d.view(n, Nq, heads, d)
         k = kv2d[:, :C].view(n, Nkv, heads, d)
         v = kv2d[:, C:].view(n, Nkv, heads, d)
-        out, lse = K.attn_fwd(q, k, v, None, False, scale)
-        ctx.dims = (n, Nq, Nkv, heads, d, scale)
+        small = K.xattn_supported(q2d.dtype, Nkv, d)
+        seed = off = 0
+        if small:
+            if drop_p > 0.0:
+                seed, off = next_dropout_stream()
+            out, lse = K.xattn_fwd(q, k, v, scale, drop_p, seed, off)
+        else:
+            if drop_p > 0.0:
+                raise NotImplementedError(f"attention dropout over {Nkv} keys: mm_xattn_* holds a query's scores in registers (<= 512 keys)")
+            out, lse = K.attn_fwd(q, k, v, None, False, scale)
+        ctx.dims = (n, Nq, Nkv, heads, d, scale, drop_p, seed, off, small)
         ctx.save_for_backward(q2d, kv2d, out, lse)
         return out.view(n * Nq, C)
 
     @staticmethod
     def backward(ctx, dout):
         q2d, kv2d, out, lse = ctx.saved_tensors
-        n, Nq, Nkv, heads, d, scale = ctx.dims
+        n, Nq, Nkv, heads, d, scale, drop_p, seed, off, small = ctx.dims
         C = heads * d
-        mk = torch.zeros_like if q2d.dtype == torch.float32 else torch.empty_like
+        mk = torch.zeros_like if (q2d.dtype == torch.float32 and not small) else torch.empty_like
         dq2d, dkv2d = mk(q2d), mk(kv2d)
-        K.attn_bwd(q2d.view(n, Nq, heads, d), kv2d[:, :C].view(n, Nkv, heads, d), kv2d[:, C:].view(n, Nkv, heads, d), out,
-                   dout.contiguous().view(n, Nq, heads, d), lse, None, False, scale, dq2d.view(n, Nq, heads, d),
-                   dkv2d[:, :C].view(n, Nkv, heads, d), dkv2d[:, C:].view(n, Nkv, heads, d))
-        return dq2d, dkv2d, None, None, None, None, None, None
+        args = (q2d.view(n, Nq, heads, d), kv2d[:, :C].view(n, Nkv, heads, d), kv2d[:, C:].view(n, Nkv, heads, d), out,
+                dout.contiguous().view(n, Nq, heads, d), lse)
+        grads = (dq2d.view(n, Nq, heads, d), dkv2d[:, :C].view(n, Nkv, heads, d), dkv2d[:, C:].view(n, Nkv, heads, d))
+        if small:
+            K.xattn_bwd(*args, scale, drop_p, seed, off, *grads)
+        else:
+            K.attn_bwd(*args, None, False, scale, *grads)
+        return dq2d, dkv2d, None, None, None, None, None, None, None
 
 
-def cross_attention(q2d, kv2d, n, Nq, Nkv, heads, d, scale):
-    return CrossAttentionFn.apply(q2d, kv2d, n, Nq, Nkv, heads, d, scale)
+def cross_attention(q2d, kv2d, n, Nq, Nkv, heads, d, scale, drop_p=0.0):
+    return CrossAttentionFn.apply(q2d, kv2d, n, Nq, Nkv, heads, d, scale, float(drop_p))
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout (attention.py:41,98 `proj_drop`): y = x * keep / (1 - p); the mask is regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.stream = (p,) + next_dropout_stream()
+        return K.dropout(x, *ctx.stream)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.dropout(dy, *ctx.stream), None
+
+
+def dropout(x, p, training=True):
+    return DropoutFn.apply(x, float(p)) if (training and p > 0.0) else x
 
 
 class ExpertFuseFn(torch.autograd.Function):
@@ -446,16 +526,7 @@ class SwiGLUMLPFn(torch.autograd.Function):
             dy = dy.contiguous()
         dres = dy if ctx.has_res else None
 
-        def wgrad(d_out, inp, group):
-            if not group.requires_grad:
-                return
-            if _is_deferred(group.params[0]):
-                _defer["items"].append((d_out, inp, group))
-            else:
-                g, acc = group.grad_target()
-                K.linear_wgrad(d_out, inp, g, acc, sumsq=group.sumsq_slots())
-                group.ready()
-
+        wgrad = _wgrad
         wgrad(dy, act, wd)
         dgu = K.gemm_swiglu_bwd(dy, wd.tensor(), gu, I)
         if dgu is None:

@@ -409,6 +409,58 @@ def attn_decode(q, k, v, key_mask, scale):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ small cross-attention + dropout
+def xattn_supported(dtype, Nkv, D):
+    """Shapes mm_xattn_* takes: up to 512 keys; bf16 head widths that are multiples of 8 up to 512, any fp32 width whose
+    score / query rows fit the wave-per-row kernel's LDS."""
+    if Nkv > 512:
+        return False
+    if dtype == torch.bfloat16:
+        return D % 8 == 0 and D <= 512
+    return dtype == torch.float32 and (2 * Nkv + 2 * D) * 4 <= 60000
+
+
+def xattn_fwd(q, k, v, scale, drop_p=0.0, seed=0, offset=0):
+    """q [n,Nq,H,D], k/v [n,Nkv,H,D] (strided views ok) -> out [n,Nq,H,D] contiguous, lse [n,H,Nq] f32; attention-probability
+    dropout with probability drop_p from the Philox stream (seed, offset) (see include/mm_hip.h)."""
+    n, Nq, H, D = q.shape
+    Nkv = k.shape[1]
+    out = torch.empty((n, Nq, H, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((n, H, Nq), dtype=torch.float32, device=q.device)
+    call("mm_xattn_fwd", dt(q), _p(q), _p(k), _p(v), n, Nq, Nkv, H, D, *_strides3(q), *_strides3(k), *_strides3(v), float(scale),
+         float(drop_p), int(seed), int(offset), _p(out), _p(lse), _stream())
+    return out, lse
+
+
+def xattn_bwd(q, k, v, out, dout, lse, scale, drop_p, seed, offset, dq, dk, dv):
+    """dq/dk/dv: preallocated views with the SAME strides as q/k/v.  Deterministic (no atomics)."""
+    import ctypes
+    n, Nq, H, D = q.shape
+    Nkv = k.shape[1]
+    assert _strides3(dq) == _strides3(q) and _strides3(dk) == _strides3(k) and _strides3(dv) == _strides3(v)
+    assert dout.is_contiguous() and out.is_contiguous()
+    nb = ctypes.c_int64(0)
+    call("mm_xattn_ws_bytes", dt(q), n, Nq, Nkv, H, ctypes.byref(nb))
+    ws = torch.empty(max(nb.value, 16), dtype=torch.uint8, device=q.device)
+    call("mm_xattn_bwd", dt(q), _p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), n, Nq, Nkv, H, D, *_strides3(q), *_strides3(k),
+         *_strides3(v), float(scale), float(drop_p), int(seed), int(offset), _p(dq), _p(dk), _p(dv), _p(ws), nb.value, _stream())
+
+
+def dropout(x, p, seed, offset):
+    """y = x * keep / (1 - p) with keep from the Philox stream (seed, offset); its own adjoint (apply it to dy)."""
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    call("mm_dropout", dt(x), _p(x), x.numel(), float(p), int(seed), int(offset), _p(y), _stream())
+    return y
+
+
+def dropout_mask(seed, offset, n, p, device="cuda"):
+    """keep flags (uint8) of elements 0 .. n-1 of the Philox stream (seed, offset): what mm_dropout / mm_xattn_* apply (tests)."""
+    m = torch.empty(n, dtype=torch.uint8, device=device)
+    call("mm_dropout_mask", int(seed), int(offset), n, float(p), _p(m), _stream())
+    return m
+
+
 # ------------------------------------------------------------------------------------------------ activations
 def swiglu_fwd(gu, I):
     M = gu.shape[0]

@@ -14,14 +14,16 @@ cross-attention is three biased GEMMs + the non-causal flash-attention kernel (N
 Parameter names equal the reference's (`experts.{e}.*`, `cross_attn.{q,k,v}_proj / proj`, `projector.projection.{0,2,4}`).
 
 `moe_meditron_clip_pep` (per-expert projection) gives every expert its own MLP projector (`projectors.{e}.projection.{0,2,4}`)
-and fuses in the LLM's embedding space; its cross-attention therefore has `hidden_size / cross_attn_heads`-wide heads, which the
-bf16 attention kernels tile only for 64 and 128 (a ValueError otherwise: no silent fallback).
+and fuses in the LLM's embedding space; its cross-attention therefore has `hidden_size / cross_attn_heads`-wide heads: 512 in the
+shipped recipe (cookbook/sft/moe/*/attn/pep: 4096 / 8), 96 in the shared-projector one (768 / 8).  Neither is a flash-kernel
+width; both run on the one-pass cross-attention kernel `mm_xattn_*` (csrc/mm_xattn.hip: up to 512 keys, head widths up to 512).
 
 NOT built: the reference's `GatingNetwork` is a torchvision ResNet-50 (moe/gating.py:37-89); torchvision is
 absent and a ResNet is outside the hot path.  `gating_network` is therefore a plug: any callable with the reference's output
 contract `pixels [n,3,H,W] -> (logits [n,E], topk_indices, weights [n,E])`.  The experts run side by side, each on its own HIP
-stream (`_run_experts`); a grouped multi-expert GEMM launch would be the step after that.  `CrossAttention`'s dropout (p = 0.1, active in the
-reference whenever the module is in train mode) is not implemented: outputs equal the reference in eval mode."""
+stream (`_run_experts`); a grouped multi-expert GEMM launch would be the step after that.  `CrossAttention`'s two dropouts
+(p = 0.1 on the attention probabilities and on the output projection, active in the reference whenever the module trains) are
+Philox-based: eval mode equals the reference, train mode equals it in distribution (torch's generator cannot be reproduced)."""
 from __future__ import annotations
 
 from typing import Any, Callable, Dict, List, Optional
@@ -82,7 +84,10 @@ class MOEImageProcessor(BaseModalityProcessor):
 
 
 class CrossAttention(nn.Module):
-    """reference model/attention.py:5-101 (eval-mode semantics: see the module docstring)."""
+    """reference model/attention.py:5-101.  `attn_drop` acts on the attention probabilities and `proj_drop` on the output of
+    `proj`, both only while the module trains (nn.Dropout semantics); the masks come from Philox streams keyed by torch's seed
+    (functional.next_dropout_stream), so they differ from torch's own generator draw for draw: eval mode equals the reference,
+    train mode equals it in distribution (tests/test_xattn_gpu.py holds the kernels to a torch restatement on the SAME mask)."""
 
     def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = False, attn_drop: float = 0.1, proj_drop: float = 0.1,
                  dtype=None, device=None):
@@ -100,15 +105,28 @@ class CrossAttention(nn.Module):
 
     def forward(self, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
         """x [n, Nq, C] queries, context [n, Nkv, C] (the specialists' tokens, already concatenated along the sequence)."""
+        from ... import kernels as K
         n, Nq, C = x.shape
         Nkv = context.shape[1]
-        hw = Fm.attention_head_width(self.head_dim, x.dtype)
-        if hw != self.head_dim:
-            raise ValueError(f"cross-attention head width {self.head_dim} is not tiled by the bf16 attention kernels (64 / 128)")
+        h, d = self.num_heads, self.head_dim
+        drop = self.attn_drop_p if self.training else 0.0
         q = self.q_proj(x.reshape(n * Nq, C))
         kv = Fm.linear(context.reshape(n * Nkv, C), self._wkv, self._bkv, dummy=grad_dummy(self.k_proj.weight))
-        o = Fm.cross_attention(q, kv, n, Nq, Nkv, self.num_heads, self.head_dim, self.scale)
-        return self.proj(o).view(n, Nq, C)
+        if K.xattn_supported(x.dtype, Nkv, d):
+            # the one-pass kernel: any head width up to 512 (the shipped recipes: 768 / 8 = 96 and 4096 / 8 = 512), dropout inside
+            o = Fm.cross_attention(q, kv, n, Nq, Nkv, h, d, self.scale, drop)
+        else:
+            # more than 512 keys: the flash kernels, narrower heads zero-padded to 64 / 128 as the SigLIP tower's are
+            if drop > 0.0:
+                raise NotImplementedError(f"attention dropout over {Nkv} keys is not built (mm_xattn_* holds <= 512 keys per query)")
+            hw = Fm.attention_head_width(d, x.dtype)
+            if hw != d:
+                q, kv = Fm.head_pad(q, h, d, hw), Fm.head_pad(kv, 2 * h, d, hw)
+            o = Fm.cross_attention(q, kv, n, Nq, Nkv, h, hw, self.scale, 0.0)
+            if hw != d:
+                o = Fm.head_strip(o, h, d, hw)
+        o = self.proj(o)
+        return Fm.dropout(o, self.proj_drop_p, self.training).view(n, Nq, C)
 
 
 def _run_experts(experts, pixels, post=None):
@@ -152,8 +170,9 @@ def _expert_stream(device, e):
     return _EXPERT_STREAMS[key]
 
 
-@AutoModality.register("moe_meditron_clip")
-class MOEImageModality(BaseModality):
+@AutoModality.register("moe_meditron_clip")             # applied last: the config class keeps the reference's model_type
+@AutoModality.register("moe_meditron_clip_shared")      # alias: the name the shipped recipes use (cookbook/sft/moe/*/*/shared/config.yaml),
+class MOEImageModality(BaseModality):                   # which the reference itself does not register (image_modality_moe.py:89)
     config_class = MOEImageConfig
     preprocessor_class = MOEImageProcessor
 

@@ -305,7 +305,10 @@ class MultiModalModelForCausalLM(nn.Module):
 
     @classmethod
     def from_pretrained(cls, path: str, device=None, strict: bool = True, **kwargs):
-        cfg = MultimodalConfig.from_dict(json.load(open(os.path.join(path, "config.json"))))
+        """`kwargs` override fields of the stored config, as HF's `from_pretrained(path, truncation=..., max_sequence_length=...)`
+        does for the reference (cli/train.py:131-137)."""
+        cfg = MultimodalConfig.from_dict(json.load(open(os.path.join(path, "config.json"))),
+                                         **{k: v for k, v in kwargs.items() if k in ("truncation", "max_sequence_length", "dtype")})
         llm_cfg = None
         p = os.path.join(path, "llm_config.json")
         if os.path.exists(p):

@@ -53,18 +53,44 @@ def cosine_with_min_lr(step: int, total: int, base_lr: float, min_lr: float, war
     return base_lr * max(0.0, factor * (1.0 - rate) + rate)
 
 
+LR_SCHEDULES = ("cosine_with_min_lr", "cosine", "linear", "constant", "constant_with_warmup")
+
+
+def scheduled_lr(kind: str, step: int, total: int, base_lr: float, min_lr: float, warmup: int = 0) -> float:
+    """HF `lr_scheduler_type` -> learning rate of optimiser step `step` (HF:optimization.py get_scheduler; the lambdas of
+    get_linear_schedule_with_warmup, get_cosine_schedule_with_warmup, get_constant_schedule(_with_warmup) and
+    get_cosine_with_min_lr_schedule_with_warmup): what the reference's recipes select through `training_args.lr_scheduler_type`."""
+    if kind == "cosine_with_min_lr":
+        return cosine_with_min_lr(step, total, base_lr, min_lr, warmup)
+    if kind == "cosine":
+        return cosine_with_min_lr(step, total, base_lr, 0.0, warmup)
+    if kind == "constant":
+        return base_lr
+    if step < warmup:
+        return base_lr * float(step) / float(max(1, warmup))
+    if kind == "constant_with_warmup" or total <= 0:
+        return base_lr
+    if kind == "linear":
+        return base_lr * max(0.0, float(total - step) / float(max(1, total - warmup)))
+    raise ValueError(f"lr_scheduler_type {kind!r}: expected one of {LR_SCHEDULES}")
+
+
 class MultimodalTrainer:
     def __init__(self, model, training_mode: TrainingMode = TrainingMode.ALIGNMENT, learning_rate: float = 1e-4,
                  weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 1.0,
                  gradient_accumulation_steps: int = 1, max_steps: int = 0, min_lr: Optional[float] = None, warmup_steps: int = 0,
                  bucket_mb: int = 256, process_group=None, data_collator=None, train_dataset=None,
-                 overlap_optimizer: bool = True):
+                 overlap_optimizer: bool = True, lr_scheduler_type: str = "cosine_with_min_lr", per_device_train_batch_size: int = 4):
         self.model = model
         self.training_mode = TrainingMode(training_mode)
         self.lr, self.wd, self.betas, self.eps = learning_rate, weight_decay, betas, eps
         self.max_grad_norm = max_grad_norm
         self.accum = max(1, gradient_accumulation_steps)
         self.max_steps, self.min_lr, self.warmup = max_steps, (min_lr if min_lr is not None else learning_rate), warmup_steps
+        if lr_scheduler_type not in LR_SCHEDULES:
+            raise ValueError(f"lr_scheduler_type {lr_scheduler_type!r}: expected one of {LR_SCHEDULES}")
+        self.lr_scheduler_type = lr_scheduler_type
+        self.per_device_train_batch_size = per_device_train_batch_size
         self.data_collator, self.train_dataset = data_collator, train_dataset
         self.step_count = 0
         self._micro = 0
@@ -73,7 +99,7 @@ class MultimodalTrainer:
         self.pg = process_group
         self.world = self.dist.get_world_size(self.pg) if self.dist else 1
         self.bucket_elems = bucket_mb * 1024 * 1024 // 2
-        self.overlap_optimizer = overlap_optimizer
+        self.overlap_optimizer = overlap_optimizer and torch.cuda.is_available()      # side HIP stream: device only
         self._set_mode()
         self._setup_state()
         self._setup_optimizer_pipeline()
@@ -88,20 +114,38 @@ class MultimodalTrainer:
         of its 14 ms stays exposed); 2-8 layers: no change.  Off under data parallelism: a held-back gradient cannot
         enter its all-reduce bucket before the end of backward.  MM_DEFER_WGRAD_LAYERS overrides the layer count (0 = off)."""
         n = int(os.environ.get("MM_DEFER_WGRAD_LAYERS", "16" if self.world == 1 else "0"))
-        tail = any(p.requires_grad for mod in self.model.modalities_with_projection for p in mod.feature_extractor.parameters()) \
-            if hasattr(self.model, "modalities_with_projection") else False
+        # a trainable modality tower (`feature_extractor` of the single-tower modalities, `experts` of the MoE ones): anything of a
+        # modality that is not its projector(s)
+        tail = any(p.requires_grad for mod in getattr(self.model, "modalities_with_projection", ())
+                   for n, p in mod.named_parameters() if not n.startswith(("projector.", "projectors.")))
         layers = getattr(getattr(self.model.model, "model", None), "layers", None)
-        if n <= 0 or not tail or layers is None or not torch.cuda.is_available():
+        side = os.environ.get("MM_WGRAD_SIDE", "0") == "1" and self.world == 1
+        if ((n <= 0 or not tail) and not side) or layers is None or not torch.cuda.is_available():
             Fm.set_wgrad_deferral(None, ())
             return
-        ids = []
-        for layer in list(layers)[:n]:
-            a, m = layer.self_attn, layer.mlp
-            for group in (a._wqkv, Fm.as_group(a.o_proj.weight), m._wgu, Fm.as_group(m.down_proj.weight)):
-                if group.requires_grad:
-                    ids.append(group.params[0])
-        self._wgrad_stream = torch.cuda.Stream()
-        Fm.set_wgrad_deferral(self._wgrad_stream, ids)
+        def firsts(ls):
+            out = []
+            for layer in ls:
+                a, m = layer.self_attn, layer.mlp
+                for group in (a._wqkv, Fm.as_group(a.o_proj.weight), m._wgu, Fm.as_group(m.down_proj.weight)):
+                    if group.requires_grad:
+                        out.append(group.params[0])
+            return out
+
+        if not tail:
+            n = 0
+        ids = firsts(list(layers)[:n])
+        # MM_WGRAD_SIDE=1 (experiment): the wgrad GEMMs of the OTHER decoder layers (and an untied lm_head) are not held back but
+        # launched at once on the side stream, beside the main stream's input-gradient chain
+        now = []
+        if os.environ.get("MM_WGRAD_SIDE", "0") == "1":
+            now = firsts(list(layers)[n:])
+            head = getattr(self.model.model, "lm_head", None)
+            if head is not None and head.weight.requires_grad and head.weight is not self.model.model.get_input_embeddings().weight:
+                now.append(head.weight)
+        prio = int(os.environ.get("MM_WGRAD_SIDE_PRIO", "0"))
+        self._wgrad_stream = torch.cuda.Stream(priority=prio)
+        Fm.set_wgrad_deferral(self._wgrad_stream, ids, immediate=now)
 
     def _setup_early_gradnorm(self):
         """Global gradient norm (clip_grad_norm_): how the sum of squares of 16.7 GB of gradients is taken.
@@ -460,7 +504,7 @@ class MultimodalTrainer:
 
     def _optimizer_step(self):
         self.step_count += 1
-        lr = cosine_with_min_lr(self.step_count - 1, self.max_steps, self.lr, self.min_lr, self.warmup)
+        lr = scheduled_lr(self.lr_scheduler_type, self.step_count - 1, self.max_steps, self.lr, self.min_lr, self.warmup)
         g = self.flat.grad
         self._norm_armed = False
         if self._norm_stream is not None and self._norm_done:
@@ -577,7 +621,7 @@ class MultimodalTrainer:
         return st
 
     def train(self, batches: Optional[Iterable[Dict[str, Any]]] = None, max_steps: Optional[int] = None,
-              resume_from_checkpoint: Optional[str] = None, per_device_train_batch_size: int = 4):
+              resume_from_checkpoint: Optional[str] = None, per_device_train_batch_size: Optional[int] = None):
         """Minimal loop: iterate collated batches, or (batches=None) collate `train_dataset` with `data_collator` in chunks
         of `per_device_train_batch_size`, staged to the device by DevicePrefetcher.  `resume_from_checkpoint` = a
         `save_state` directory (reference cli/train.py:188-195)."""
@@ -586,7 +630,7 @@ class MultimodalTrainer:
         if batches is None:
             if self.train_dataset is None or self.data_collator is None:
                 raise ValueError("train(): give `batches`, or construct the trainer with train_dataset and data_collator")
-            ds, bs, coll = self.train_dataset, per_device_train_batch_size, self.data_collator
+            ds, bs, coll = self.train_dataset, per_device_train_batch_size or self.per_device_train_batch_size, self.data_collator
             rank = self.dist.get_rank(self.pg) if self.dist else 0
 
             def gen():      # contiguous chunks, strided over ranks (each rank sees a disjoint share)

@@ -67,7 +67,7 @@ def _build(meta, w, v, fusion, dtype, tmp):
     FlatParams([(k, p, "projector" if k.startswith("projector") else "encoder") for k, p in own.items()], "cuda", dtype)
     for p in m.parameters():
         p.requires_grad_(True)
-    return m
+    return m.eval()          # the fixtures were made by the reference in eval mode: CrossAttention's dropouts are off
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -126,3 +126,47 @@ def test_moe_pep_fusions_match_reference(moe_pep, tmp_path, fusion, dtype):
         assert rel(g.float().reshape(ref.shape), ref) < tol_g, key
         n += 1
     assert n >= 10
+
+
+@pytest.mark.parametrize("pep", [False, True])
+def test_shipped_cross_attn_recipes_construct_and_train(tmp_path, pep):
+    """The two cross-attention recipes the reference ships (cookbook/sft/moe/*/attn/shared and .../attn/pep: five ViT-B/32 experts,
+    hidden 4096, 8 cross-attention heads => head widths 768 / 8 = 96 and 4096 / 8 = 512) construct in bf16 and take a training
+    step (train mode: both dropouts active).  Towers cut to 2 layers to keep the test small; widths, patch grid (P = 49), expert
+    count and head counts are the recipes'."""
+    from multimeditron_amd.model.modalities import AutoModality, MOEImageConfig, MOEImageConfigPEP
+    from multimeditron_amd.model.presets import resolve_vision_config
+    from multimeditron_amd.nn import FlatParams
+    vis = dict(resolve_vision_config("openai/clip-vit-base-patch32"), num_hidden_layers=2)
+    dirs = []
+    for e in range(5):
+        d = os.path.join(str(tmp_path), f"expert{e}")
+        os.makedirs(d, exist_ok=True)
+        json.dump({"vision_config": vis}, open(os.path.join(d, "config.json"), "w"))
+        dirs.append(d)
+    kw = dict(hidden_size=4096, expert_clip_names=dirs, image_processor=dirs[0], gating_path="stub", top_k_experts=5,
+              generalist_idx=-1, fusion_method="cross_attn")
+    cfg = (MOEImageConfigPEP if pep else MOEImageConfig)(**kw)
+    assert cfg.model_type == ("moe_meditron_clip_pep" if pep else "moe_meditron_clip")
+    assert AutoModality._cls("moe_meditron_clip_shared") is AutoModality._cls("moe_meditron_clip")      # the recipes' spelling
+
+    def gate(px):
+        logits = px.float().mean(dim=(2, 3)) @ torch.ones(5, 3, device=px.device) * torch.arange(5, device=px.device).float()
+        return logits, logits.topk(1, dim=-1).indices, torch.softmax(logits, dim=-1)
+
+    torch.manual_seed(0)
+    m = AutoModality.model_from_config(cfg, dtype=torch.bfloat16, device="cuda", gating_network=gate)
+    assert m.cross_attn.head_dim == (512 if pep else 96)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            torch.nn.init.normal_(p, std=0.02) if p.dim() > 1 else (torch.nn.init.ones_(p) if "norm" in k or "layrnorm" in k else torch.nn.init.zeros_(p))
+    FlatParams([(k, p, "projector" if "projector" in k else "encoder") for k, p in m.named_parameters()], "cuda", torch.bfloat16)
+    m.train()
+    px = [torch.randn(3, 224, 224) for _ in range(3)]
+    y = m(px)
+    assert y.shape == (3, 49, 4096)
+    y.float().square().mean().backward()
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad.float()).all(), k
+    assert float(m.cross_attn.q_proj.weight.grad.float().abs().sum()) > 0
