@@ -307,8 +307,21 @@ class MultiModalModelForCausalLM(nn.Module):
     def from_pretrained(cls, path: str, device=None, strict: bool = True, **kwargs):
         """`kwargs` override fields of the stored config, as HF's `from_pretrained(path, truncation=..., max_sequence_length=...)`
         does for the reference (cli/train.py:131-137)."""
-        cfg = MultimodalConfig.from_dict(json.load(open(os.path.join(path, "config.json"))),
-                                         **{k: v for k, v in kwargs.items() if k in ("truncation", "max_sequence_length", "dtype")})
+        raw = json.load(open(os.path.join(path, "config.json")))
+
+        def local(name):      # a relative model directory stored beside the checkpoint (the reference resolves it against the cwd)
+            if isinstance(name, str) and not os.path.isabs(name) and not os.path.isdir(name) and os.path.isdir(os.path.join(path, name)):
+                return os.path.join(path, name)
+            return name
+
+        raw["llm_path"] = local(raw.get("llm_path"))
+        for m in raw.get("modalities", []):
+            for key in ("clip_name", "image_processor"):
+                if key in m:
+                    m[key] = local(m[key])
+            if "expert_clip_names" in m:
+                m["expert_clip_names"] = [local(x) for x in m["expert_clip_names"]]
+        cfg = MultimodalConfig.from_dict(raw, **{k: v for k, v in kwargs.items() if k in ("truncation", "max_sequence_length", "dtype")})
         llm_cfg = None
         p = os.path.join(path, "llm_config.json")
         if os.path.exists(p):

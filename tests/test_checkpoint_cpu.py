@@ -87,3 +87,42 @@ def test_checkpoint_needs_no_side_file_when_llm_path_resolves(tmp_path):
     m2 = MultiModalModelForCausalLM.from_pretrained(str(out), device="cpu")
     for (k1, p1), (k2, p2) in zip(m.named_parameters(), m2.named_parameters()):
         assert k1 == k2 and torch.equal(p1.detach(), p2.detach())
+
+
+def test_loads_a_directory_the_reference_wrote(golden_dir):
+    """tests/golden/ckpt_ref/ = what the REFERENCE's `save_pretrained` leaves (tools/make_golden.py ckpt_fixture): config.json in
+    `MultimodalConfig.to_dict` layout with HF's PretrainedConfig fields inside every modality entry (model.py:152-202), and
+    model.safetensors under the reference's names, the unused CLIP text tower / projections / logit_scale included.  Strict load:
+    every parameter of the build comes from the file, bit for bit; only the known-unused reference keys are set aside.  (The other
+    direction -- the reference loading a directory the build wrote and reproducing its logits exactly -- can only run where the
+    reference is importable: tools/make_golden.py asserts it and records it in fixture.meta.json.)"""
+    from safetensors.torch import load_file
+    from multimeditron_amd.model.model import MultiModalModelForCausalLM
+    d = os.path.join(golden_dir, "ckpt_ref")
+    meta = json.load(open(os.path.join(d, "fixture.meta.json")))
+    assert meta["reference_loads_build_checkpoint"] is True and meta["max_abs_logit_diff_reference_vs_reference_via_build"] == 0.0
+    raw = json.load(open(os.path.join(d, "config.json")))
+    assert raw["model_type"] == "multimodal" and "id2label" in raw["modalities"][0]       # HF noise the reference's to_dict carries
+    m = MultiModalModelForCausalLM.from_pretrained(d, device="cpu", strict=True)
+    sd = load_file(os.path.join(d, "model.safetensors"))
+    own = dict(m.named_parameters())
+    assert set(own) <= set(sd)
+    for k, p in own.items():
+        assert torch.equal(p.detach().float(), sd[k].float().reshape(p.shape)), k
+    unused = sorted(set(sd) - set(own))
+    assert unused and all(any(t in k for t in m._IGNORABLE) for k in unused), unused[:5]
+    assert any("text_model" in k for k in unused)
+    c = m.config
+    assert (c.vocab_size, c.eos_token_idx, c.hidden_size, c.padding_side, c.truncation) == (130, 129, 128, "left", False)
+    assert c.modalities[0].model_type == "meditron_clip" and os.path.isdir(c.modalities[0].clip_name)      # clip/ beside the checkpoint
+    # a truncated / foreign file is an error, not a silent random init
+    import pytest
+    import shutil
+    from safetensors.torch import save_file
+    bad = os.path.join(str(__import__("tempfile").mkdtemp()), "ck")
+    shutil.copytree(d, bad)
+    t = dict(sd)
+    t.pop("model.model.layers.0.mlp.down_proj.weight")
+    save_file(t, os.path.join(bad, "model.safetensors"), metadata={"format": "pt"})
+    with pytest.raises(RuntimeError, match="down_proj"):
+        MultiModalModelForCausalLM.from_pretrained(bad, device="cpu", strict=True)

@@ -232,3 +232,26 @@ def test_bf16_decode_ids_vs_oracle(gold, model_bf16):
             assert 0 <= gap < 0.05 * float(lg.std()) + 2e-2, (b, i, gap, float(lg.std()))
             break
     assert agreed >= ids.shape[0] * n // 2, (ids, ref)       # most steps agree outright
+
+
+def test_reference_written_checkpoint_reproduces_reference_logits(golden_dir):
+    """tests/golden/ckpt_ref/: the directory the REFERENCE's save_pretrained wrote, loaded by `from_pretrained` onto the GPU, must give
+    the logits the reference computed from the same weights before saving (fp32 path, 1e-4 rel-L2, arg-max identical)."""
+    import os
+    from safetensors.torch import load_file
+    from multimeditron_amd.model.model import MultiModalModelForCausalLM
+    d = os.path.join(golden_dir, "ckpt_ref")
+    v = load_file(os.path.join(d, "vectors.safetensors"))
+    m = MultiModalModelForCausalLM.from_pretrained(d, device="cuda", strict=True).eval()
+    px = v["in.pixels"]
+    batch = dict(input_ids=v["in.input_ids"].cuda(), attention_mask=v["in.attention_mask"].cuda(), position_ids=v["in.position_ids"].cuda(),
+                 labels=v["in.labels"].cuda(),
+                 processed_multimodal_inputs={"batch_idx": {"image": v["in.batch_idx"].cuda()}, "token_range": {"image": v["in.token_range"].cuda()},
+                                              "stacked": {"image": [px[i] for i in range(px.shape[0])]}})
+    with torch.no_grad():
+        o = m(**batch)
+    keep = v["in.attention_mask"].bool()
+    got, ref = o.logits.float().cpu()[keep], v["logits"][keep]
+    assert float((got - ref).norm() / ref.norm()) < 1e-4
+    assert torch.equal(got.argmax(-1), ref.argmax(-1))
+    assert abs(float(o.loss) - float(v["loss"])) < 1e-4 * max(1.0, abs(float(v["loss"])))

@@ -113,19 +113,9 @@ def qwen2_cfg():
                        rope_parameters={"rope_type": "default", "rope_theta": 1000000.0})
 
 
-def build_model(llm_cfg, seed, tmp):
-    d1 = os.path.join(tmp, "clip")
-    d2 = os.path.join(tmp, "llm")
-    os.makedirs(d1, exist_ok=True)
-    os.makedirs(d2, exist_ok=True)
-    make_clip_dir(d1, seed)
-    llm_cfg.save_pretrained(d2)
-    torch.manual_seed(seed + 7)
-    cfg = MultimodalConfig(vocab_size=VOCAB, modalities=[ImageConfig(hidden_size=128, clip_name=d1)],
-                           llm_path=d2, dtype="float32", eos_token_idx=EOS, hidden_size=128)
-    model = MultiModalModelForCausalLM(cfg)
-    # Re-randomise everything deterministically (post_init policies differ between HF versions),
-    # then round to bf16-representable values so bf16 and fp32 consumers see identical weights.
+def randomize_(model, seed):
+    """Re-randomise everything deterministically (post_init policies differ between HF versions), then round to
+    bf16-representable values so bf16 and fp32 consumers see identical weights."""
     g = torch.Generator().manual_seed(seed + 11)
     with torch.no_grad():
         seen = set()
@@ -143,6 +133,20 @@ def build_model(llm_cfg, seed, tmp):
             else:
                 p.copy_(0.06 * torch.randn(p.shape, generator=g))
             bf16_round_(p)
+
+
+def build_model(llm_cfg, seed, tmp):
+    d1 = os.path.join(tmp, "clip")
+    d2 = os.path.join(tmp, "llm")
+    os.makedirs(d1, exist_ok=True)
+    os.makedirs(d2, exist_ok=True)
+    make_clip_dir(d1, seed)
+    llm_cfg.save_pretrained(d2)
+    torch.manual_seed(seed + 7)
+    cfg = MultimodalConfig(vocab_size=VOCAB, modalities=[ImageConfig(hidden_size=128, clip_name=d1)],
+                           llm_path=d2, dtype="float32", eos_token_idx=EOS, hidden_size=128)
+    model = MultiModalModelForCausalLM(cfg)
+    randomize_(model, seed)
     return model.eval()
 
 
@@ -553,6 +557,92 @@ WORDS = ("<|eot_id|> <|start_header_id|> <|end_header_id|> <|image_start|> <|ima
          "camera you are helpful and there two pictures first second nice").split()
 
 
+def ckpt_fixture(name="ckpt_ref", seed=700):
+    """A checkpoint directory written by the REFERENCE's own `save_pretrained` (HF PreTrainedModel.save_pretrained on the reference
+    class: config.json in `MultimodalConfig.to_dict` layout, model.py:152-202, + model.safetensors under the reference's parameter
+    names, the unused CLIP text tower included), committed as data under tests/golden/ckpt_ref/ together with the logits the
+    reference computes from it.  `clip_name` / `llm_path` are the relative directories clip/ and llm/ inside it (config files only).
+
+    Second direction, checked here because the reference only runs in this container: the BUILD loads that directory, writes its
+    own `save_pretrained` output, and the REFERENCE's `from_pretrained` loads that and must reproduce the same logits."""
+    import shutil
+    d = os.path.join(OUT, name)
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    cwd = os.getcwd()
+    os.chdir(d)
+    try:
+        make_clip_dir("clip", seed)
+        llama_cfg().save_pretrained("llm")
+        torch.manual_seed(seed + 7)
+        cfg = MultimodalConfig(vocab_size=VOCAB, modalities=[ImageConfig(hidden_size=128, clip_name="clip")], llm_path="llm",
+                               dtype="float32", eos_token_idx=EOS, hidden_size=128)
+        model = MultiModalModelForCausalLM(cfg)
+        randomize_(model, seed)
+        model.eval()
+        model.save_pretrained(".", safe_serialization=True)
+        batch = make_batch(seed + 1, 40, [[3], [1, 20]], "right")
+        with torch.no_grad():
+            o = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], position_ids=batch["position_ids"],
+                      labels=batch["labels"], processed_multimodal_inputs=batch["processed_multimodal_inputs"])
+        vec = {"logits": o.logits.float(), "loss": o.loss.float().reshape(1)}
+        for k in ("input_ids", "attention_mask", "position_ids", "labels"):
+            vec[f"in.{k}"] = batch[k].clone()
+        pmi = batch["processed_multimodal_inputs"]
+        vec["in.batch_idx"], vec["in.token_range"] = pmi["batch_idx"]["image"].clone(), pmi["token_range"]["image"].clone()
+        vec["in.pixels"] = torch.stack(pmi["stacked"]["image"]).clone()
+        save_file({k: v.contiguous() for k, v in vec.items()}, "vectors.safetensors")
+        # ---- build -> reference
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from multimeditron_amd.model.model import MultiModalModelForCausalLM as Ours
+        ours = Ours.from_pretrained(".", device="cpu", strict=True)
+        back = tempfile.mkdtemp(prefix="build_ckpt_")
+        ours.save_pretrained(back)
+        # The reference's own `from_pretrained` cannot run under transformers 5.15, not even on the directory it has just written:
+        # HF builds the model under a meta-device context and ImageModality.__init__ calls AutoModel.from_pretrained inside it
+        # (image_modality.py:124) -> RuntimeError.  Recorded in the fixture's meta; the reverse direction is therefore checked
+        # the way HF's loader ends: a reference-constructed model + load_state_dict of the file the build wrote.
+        own_error = None
+        try:
+            MultiModalModelForCausalLM.from_pretrained(".")
+        except Exception as e:                                   # noqa: BLE001
+            own_error = f"{type(e).__name__}: {str(e).splitlines()[0]}"[:200]
+        from safetensors.torch import load_file
+        torch.manual_seed(seed + 99)                             # different init: every tensor that matters must come from the file
+        # (return_unused_kwargs=True: the only branch of the reference's from_dict that works, SURVEY Appendix B)
+        ref2 = MultiModalModelForCausalLM(MultimodalConfig.from_dict(json.load(open(os.path.join(back, "config.json"))),
+                                                                      return_unused_kwargs=True)[0])
+        res = ref2.load_state_dict(load_file(os.path.join(back, "model.safetensors")), strict=False)
+        info = {"missing_keys": list(res.missing_keys), "unexpected_keys": list(res.unexpected_keys)}
+        ref2.eval()
+        with torch.no_grad():
+            o2 = ref2(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], position_ids=batch["position_ids"],
+                      labels=batch["labels"], processed_multimodal_inputs=batch["processed_multimodal_inputs"])
+        diff = float((o2.logits.float() - o.logits.float()).abs().max())
+        missing = sorted(info.get("missing_keys", []))
+        unexpected = sorted(info.get("unexpected_keys", []))
+        assert diff == 0.0, diff
+        assert not unexpected, unexpected[:5]
+        assert all(("text_model" in k or "text_projection" in k or "visual_projection" in k or "logit_scale" in k or "post_layernorm" in k)
+                   for k in missing), [k for k in missing if "text_model" not in k][:5]
+        shutil.rmtree(back, ignore_errors=True)
+        meta = {"written_by": "reference MultiModalModelForCausalLM.save_pretrained (transformers %s)" % transformers.__version__,
+                "files": sorted(f for f in os.listdir(".") if os.path.isfile(f)),
+                "reference_loads_build_checkpoint": True, "max_abs_logit_diff_reference_vs_reference_via_build": diff,
+                "reference_from_pretrained_on_its_own_directory": own_error or "ok",
+                "keys_the_build_does_not_write": len(missing), "vocab_size": VOCAB, "eos_token_idx": EOS,
+                "llm": json.load(open("llm/config.json")), "vision": VIS}
+        with open("fixture.meta.json", "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        # the CLIP weights live in the checkpoint itself; the tower directory keeps its config files only
+        for fn in os.listdir("clip"):
+            if fn.endswith((".safetensors", ".bin")):
+                os.remove(os.path.join("clip", fn))
+        print(name, "files", meta["files"], "| reference <- build: max |dlogits| =", diff, "| keys left to re-init:", len(missing))
+    finally:
+        os.chdir(cwd)
+
+
 def make_tokenizer():
     from tokenizers import Tokenizer, models, pre_tokenizers
     vocab = {w: i for i, w in enumerate(WORDS)}
@@ -676,7 +766,7 @@ def collator_fixture():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["llama", "qwen2", "llama_d128", "siglip", "moe", "moe_pep", "collator"]
+    which = sys.argv[1:] or ["llama", "qwen2", "llama_d128", "siglip", "moe", "moe_pep", "collator", "ckpt"]
     if "llama" in which:
         model_fixture("tiny_clip_llama", llama_cfg(), 100)
     if "qwen2" in which:
@@ -691,3 +781,5 @@ if __name__ == "__main__":
         moe_fixture("tiny_moe_clip_pep", 600, pep=True)
     if "collator" in which:
         collator_fixture()
+    if "ckpt" in which:
+        ckpt_fixture()
