@@ -22,22 +22,45 @@ import torch
 
 
 class _Bucket:
-    __slots__ = ("start", "end", "params", "pending", "work")
+    __slots__ = ("start", "end", "params", "pending", "work", "q")
 
     def __init__(self, start, end):
         self.start, self.end, self.params, self.pending, self.work = start, end, [], 0, None
+        self.q = 0           # sharded exchange: elements per rank of the reduce-scattered part [start, start + world * q)
+
+    def shard(self, rank, world):
+        """-> (s, e) of rank's 1/world share of the reduce-scattered part, and (ts, te) of the tail every rank keeps whole."""
+        s = self.start + rank * self.q
+        return (s, s + self.q), (self.start + world * self.q, self.end)
+
+
+class _Works:
+    """several collectives of one bucket behind the Work interface (wait() orders the current stream after all of them)"""
+    __slots__ = ("works",)
+
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
 
 
 class GradExchanger:
     def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], segments: Sequence[Tuple[int, int, int]],
-                 bucket_elems: int, dist=None, group=None, force: bool = False, comm=None):
+                 bucket_elems: int, dist=None, group=None, force: bool = False, comm=None, sharded: bool = False):
         """ranges: trainable [start,end) of flat_grad; segments: (param_key, start, end) for every trainable param.
-        comm: an `RcclComm` to carry the buckets instead of dist.all_reduce (dist stays the control channel)."""
+        comm: an `RcclComm` to carry the buckets instead of dist.all_reduce (dist stays the control channel).
+        sharded: REDUCE-SCATTER instead of all-reduce (the sharded optimiser step, reference config/deepspeed.json:5-19): after the
+        exchange rank r holds the summed gradient of its 1/world share of every bucket only (`_Bucket.shard`), plus the bucket's
+        tail (fewer than 8 * world elements, all-reduced) which every rank keeps; `all_gather_params` is the other half."""
         self.grad = flat_grad
         self.dist, self.group = dist, group
         self.comm = comm
         self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
         self.force = force
+        self.sharded = bool(sharded) and dist is not None
         self.buckets: List[_Bucket] = []
         for s, e in ranges:
             a = s
@@ -45,6 +68,9 @@ class GradExchanger:
                 b = min(e, a + bucket_elems)
                 self.buckets.append(_Bucket(a, b))
                 a = b
+        if self.sharded:
+            for bk in self.buckets:
+                bk.q = (bk.end - bk.start) // (8 * self.world) * 8           # shards start on 16-byte boundaries
         self.param_buckets: Dict[int, List[_Bucket]] = {}
         for key, s, e in segments:
             for bk in self.buckets:
@@ -95,6 +121,9 @@ class GradExchanger:
                 self.launched_early += 1
 
     def _launch(self, bk: _Bucket):
+        if self.sharded:
+            bk.work = self._reduce_scatter(bk)
+            return
         if self.comm is not None:
             bk.work = self.comm.all_reduce(self.grad[bk.start:bk.end])
             return
@@ -121,3 +150,32 @@ class GradExchanger:
 
     def written(self, key: int) -> bool:
         return self._count.get(key, 0) > 0
+
+    # ------------------------------------------------------------------ sharded exchange (reduce-scatter / all-gather)
+    def _reduce_scatter(self, bk: _Bucket):
+        """rank r's share of the bucket's sum lands IN PLACE in its share of the gradient buffer (the other shares are left with
+        partial data nobody reads); the tail is all-reduced."""
+        d, g, W = self.dist, self.grad, self.world
+        (s, e), (ts, te) = bk.shard(self.rank, W)
+        works = []
+        if bk.q > 0:
+            main = g[bk.start:ts]
+            if self.comm is not None:
+                works.append(self.comm.reduce_scatter(main))
+            else:
+                works.append(d.reduce_scatter_tensor(g[s:e], main, op=d.ReduceOp.SUM, group=self.group, async_op=True))
+        if te > ts:
+            works.append(self.comm.all_reduce(g[ts:te]) if self.comm is not None else
+                         d.all_reduce(g[ts:te], op=d.ReduceOp.SUM, group=self.group, async_op=True))
+        return _Works(works)
+
+    def all_gather_params(self, flat_data: torch.Tensor, bk: _Bucket):
+        """The other half: every rank has updated its share of the bucket's parameters (and the whole tail); collect the shares in
+        place.  Enqueued behind the CURRENT stream's work (the optimiser's side stream); returns a Work."""
+        if bk.q == 0:
+            return _Works([])
+        (s, e), (ts, _) = bk.shard(self.rank, self.world)
+        main = flat_data[bk.start:ts]
+        if self.comm is not None:
+            return _Works([self.comm.all_gather(main)])
+        return _Works([self.dist.all_gather_into_tensor(main, flat_data[s:e], group=self.group, async_op=True)])

@@ -80,7 +80,8 @@ class MultimodalTrainer:
                  weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 1.0,
                  gradient_accumulation_steps: int = 1, max_steps: int = 0, min_lr: Optional[float] = None, warmup_steps: int = 0,
                  bucket_mb: int = 256, process_group=None, data_collator=None, train_dataset=None,
-                 overlap_optimizer: bool = True, lr_scheduler_type: str = "cosine_with_min_lr", per_device_train_batch_size: int = 4):
+                 overlap_optimizer: bool = True, lr_scheduler_type: str = "cosine_with_min_lr", per_device_train_batch_size: int = 4,
+                 shard_optimizer: Optional[bool] = None):
         self.model = model
         self.training_mode = TrainingMode(training_mode)
         self.lr, self.wd, self.betas, self.eps = learning_rate, weight_decay, betas, eps
@@ -100,6 +101,13 @@ class MultimodalTrainer:
         self.world = self.dist.get_world_size(self.pg) if self.dist else 1
         self.bucket_elems = bucket_mb * 1024 * 1024 // 2
         self.overlap_optimizer = overlap_optimizer and torch.cuda.is_available()      # side HIP stream: device only
+        # Sharded optimiser step under data parallelism (the reference partitions optimiser state across ranks: ZeRO stage 3,
+        # config/deepspeed.json:5-19): reduce-scatter the gradients, AdamW on this rank's 1/world share of master / m / v (only that
+        # share is allocated), all-gather the bf16 parameters under the next forward.  Parameters and gradients stay replicated
+        # (they fit HBM; no parameter gathering inside forward / backward as ZeRO-3 needs).  Default on for world > 1.
+        if shard_optimizer is None:
+            shard_optimizer = os.environ.get("MM_SHARD_OPTIM", "1") != "0"
+        self.shard_optim = bool(shard_optimizer) and self.dist is not None and (self.world > 1 or bool(os.environ.get("MM_FORCE_EXCHANGE")))
         self._set_mode()
         self._setup_state()
         self._setup_optimizer_pipeline()
@@ -162,6 +170,8 @@ class MultimodalTrainer:
             of backward: 409.2 vs 404.8 ms/step: the sweep's HBM reads slow the GEMMs they run beside.
         One GPU only in both cases: under data parallelism a gradient is final only after its bucket's all-reduce."""
         self._norm_chunks = [(s, e, None) for s, e, _ in self.ranges]       # (start, end, trigger param id or None)
+        if self.shard_optim:       # after the reduce-scatter a rank holds final gradients for its own pieces only
+            self._norm_chunks = [(a, b, None) for a, b, _, _, _, _ in self.pieces]
         self._norm_triggers: Dict[int, int] = {}
         self._norm_stream = None
         self._ss = None
@@ -274,18 +284,7 @@ class MultimodalTrainer:
         self.ranges = flat.trainable_ranges()            # [(start, end, decay)]
         if not self.ranges:
             raise ValueError("no trainable parameters in this training mode")
-        n_train = sum(e - s for s, e, _ in self.ranges)
         dev = flat.device
-        # optimizer state only for the trainable ranges, packed back to back
-        self.master = torch.empty(n_train, dtype=torch.float32, device=dev)
-        self.m = torch.zeros(n_train, dtype=torch.float32, device=dev)
-        self.v = torch.zeros(n_train, dtype=torch.float32, device=dev)
-        off = 0
-        self.state_off = []
-        for s, e, _ in self.ranges:
-            self.master[off:off + e - s].copy_(flat.data[s:e])          # device copy of the bf16 weights (plumbing)
-            self.state_off.append(off)
-            off += e - s
         segs = [(id(seg.param), seg.start, seg.end) for seg in flat.segments if seg.param.requires_grad]
         self._trainable = [seg for seg in flat.segments if seg.param.requires_grad]
         import os
@@ -300,7 +299,36 @@ class MultimodalTrainer:
             raise ValueError(f"MM_COMM={mode!r}: expected 'torch', 'abi' or 'abi-rsag'")
         self.exchanger = GradExchanger(flat.grad, [(s, e) for s, e, _ in self.ranges], segs, self.bucket_elems,
                                        dist=self.dist if (self.world > 1 or force) else None, group=self.pg, force=force,
-                                       comm=self.comm)
+                                       comm=self.comm, sharded=self.shard_optim)
+        # optimizer state: for the trainable ranges, packed back to back -- all of them (replicated), or this rank's pieces only
+        if self.shard_optim:
+            rank = self.exchanger.rank
+            decay_of = lambda a: next(d for s0, e0, d in self.ranges if s0 <= a < e0)
+            self.pieces = []                              # (start, end, decay, state offset, bucket index, replicated tail?)
+            off = 0
+            for bi, bk in enumerate(self.exchanger.buckets):
+                (s0, e0), (ts, te) = bk.shard(rank, self.world)
+                for a, b, tail in ((s0, e0, False), (ts, te, True)):
+                    if b > a:
+                        self.pieces.append((a, b, decay_of(bk.start), off, bi, tail))
+                        off += b - a
+            n_state = off
+        else:
+            self.pieces = None
+            n_state = sum(e - s for s, e, _ in self.ranges)
+        self.master = torch.empty(n_state, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.state_off = []
+        if self.shard_optim:
+            for a, b, _, o, _, _ in self.pieces:
+                self.master[o:o + b - a].copy_(flat.data[a:b])
+        else:
+            off = 0
+            for s, e, _ in self.ranges:
+                self.master[off:off + e - s].copy_(flat.data[s:e])          # device copy of the bf16 weights (plumbing)
+                self.state_off.append(off)
+                off += e - s
         if self.world > 1 and not os.environ.get("MM_GEMM_PERSIST"):
             # The GEMM's persistent grid is one resident workgroup per CU, each walking 1/256 of the tiles.  While an RCCL
             # kernel holds some CUs (its waves and an 8-wave GEMM workgroup do not fit one CU together), the workgroups that
@@ -374,6 +402,12 @@ class MultimodalTrainer:
         import re
         self._blocks = []          # [(module or None, [(start, end, decay, state_off)])] in forward order
         self._defer_from, self._deferred = None, None
+        self._hooks = []
+        self._pending = {}
+        self._all_done = None
+        if self.shard_optim:
+            self._setup_sharded_pipeline()
+            return
         if not self.overlap_optimizer:
             return
         state_off = {}
@@ -435,6 +469,91 @@ class MultimodalTrainer:
                 hooked.add(id(mod))
                 self._hooks.append(mod.register_forward_pre_hook(self._wait_block))
 
+    def _setup_sharded_pipeline(self):
+        """Sharded step: the unit of work is a BUCKET (update my share, then all-gather the bucket's parameters), in forward order
+        of what the buckets hold (modality towers and projector, the decoder's norm weights, then its matrices layer by layer); a
+        forward pre-hook on every block waits for the all-gathers of the buckets its parameters lie in."""
+        import re
+        ex = self.exchanger
+        llm_lo = min((sg.start for sg in self._trainable if sg.name.startswith("model.")), default=None)
+        llm_hi = max((sg.end for sg in self._trainable if sg.name.startswith("model.")), default=None)
+
+        def order(i):
+            bk = ex.buckets[i]
+            llm = llm_lo is not None and llm_lo <= bk.start < llm_hi
+            decay = next(d for s0, e0, d in self.ranges if s0 <= bk.start < e0)
+            return (1 if llm else 0, 1 if (llm and decay) else 0, bk.start)
+
+        self._bucket_order = sorted(range(len(ex.buckets)), key=order)
+        self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() and self.flat.device.type == "cuda" else None
+
+        def block_key(name):
+            m = re.match(r"(.*?layers\.\d+)\.", name)
+            return m.group(1) if m else name.rsplit(".", 1)[0]
+
+        groups: Dict[str, List] = {}
+        for seg in self._trainable:
+            groups.setdefault(block_key(seg.name), []).append(seg)
+        self._block_buckets: Dict[int, List[int]] = {}
+        self._eager_buckets = set()
+        for key, segs in groups.items():
+            mod = self._hook_module(key)
+            idx = sorted({bi for sg in segs for bi, bk in enumerate(ex.buckets) if sg.start < bk.end and sg.end > bk.start})
+            if mod is None:
+                self._eager_buckets.update(idx)
+            else:
+                self._block_buckets.setdefault(id(mod), [])
+                self._block_buckets[id(mod)] = sorted(set(self._block_buckets[id(mod)]) | set(idx))
+                if not any(h is mod for h in getattr(self, "_hooked_mods", [])):
+                    self._hooked_mods = getattr(self, "_hooked_mods", []) + [mod]
+                    self._hooks.append(mod.register_forward_pre_hook(self._wait_block_sharded))
+        self._gather_works: Dict[int, Any] = {}
+
+    def _wait_block_sharded(self, mod, _inputs):
+        for bi in self._block_buckets.get(id(mod), ()):
+            w = self._gather_works.pop(bi, None)
+            if w is not None:
+                w.wait()
+
+    def _optimizer_step_sharded(self, lr):
+        """clip + AdamW on this rank's pieces, then the all-gathers (see _setup_sharded_pipeline)."""
+        ex, g = self.exchanger, self.flat.grad
+        self._norm_partial.zero_()                         # slots this rank does not count must read 0 in the sum over ranks
+        for i, (a, b, _, _, _, tail) in enumerate(self.pieces):
+            if tail and ex.rank != 0:
+                continue                                   # every rank holds the tails: count them once
+            self._norm_chunk(i)
+        if self.world > 1:
+            self.dist.all_reduce(self._norm_partial, op=self.dist.ReduceOp.SUM, group=self.pg)       # a few KB of fp32 partial sums
+        total = K.gradnorm_finish(self._norm_partial, self.max_grad_norm if self.max_grad_norm else 0.0)
+        self.last_grad_norm = total
+        by_bucket: Dict[int, List] = {}
+        for pc in self.pieces:
+            by_bucket.setdefault(pc[4], []).append(pc)
+        main = torch.cuda.current_stream() if self._opt_stream is not None else None
+        if main is not None:
+            self._opt_stream.wait_stream(main)
+
+        def run():
+            for bi in self._bucket_order:
+                for a, b, decay, off, _, _ in by_bucket.get(bi, ()):
+                    n = b - a
+                    K.adamw_step(self.flat.data[a:b], g[a:b], self.master[off:off + n], self.m[off:off + n], self.v[off:off + n], lr,
+                                 self.betas[0], self.betas[1], self.eps, self.wd if decay else 0.0, self.step_count, clip=total)
+                self._gather_works[bi] = ex.all_gather_params(self.flat.data, ex.buckets[bi])
+
+        if self._opt_stream is not None:
+            with torch.cuda.stream(self._opt_stream):
+                run()
+                self._all_done = torch.cuda.Event()
+                self._all_done.record(self._opt_stream)
+        else:
+            run()
+        for bi in self._eager_buckets:                     # parameters no forward hook guards: wait right away
+            w = self._gather_works.pop(bi, None)
+            if w is not None:
+                w.wait()
+
     def _hook_module(self, key: str):
         """The module whose __call__ precedes every read of block `key`'s parameters in forward: the block's own module,
         or -- for bare parameter holders that forward never calls (`_mm_param_holder`: the ViT's patch_embedding /
@@ -492,6 +611,13 @@ class MultimodalTrainer:
 
     def _wait_optimizer(self):
         """Everything the side stream still owes (before gradients are overwritten or parameters read ad hoc)."""
+        if self.shard_optim:
+            for bi in list(getattr(self, "_gather_works", {})):
+                self._gather_works.pop(bi).wait()
+            if self._all_done is not None:
+                torch.cuda.current_stream().wait_event(self._all_done)
+                self._all_done = None
+            return
         if getattr(self, "_deferred", None) is not None:
             self._launch_deferred()                           # no forward reached the decoder since the last step
         if getattr(self, "_all_done", None) is not None:
@@ -507,6 +633,9 @@ class MultimodalTrainer:
         lr = scheduled_lr(self.lr_scheduler_type, self.step_count - 1, self.max_steps, self.lr, self.min_lr, self.warmup)
         g = self.flat.grad
         self._norm_armed = False
+        if self.shard_optim:
+            self._optimizer_step_sharded(lr)
+            return
         if self._norm_stream is not None and self._norm_done:
             torch.cuda.current_stream().wait_stream(self._norm_stream)     # the chunks summed under backward
         for i in range(len(self._norm_chunks)):
@@ -577,8 +706,16 @@ class MultimodalTrainer:
         self.model.save_pretrained(path, **kw)
 
     def _state_signature(self):
-        return {"ranges": [[int(s), int(e), bool(d)] for s, e, d in self.ranges], "training_mode": self.training_mode.name,
-                "numel": int(self.master.numel())}
+        sig = {"ranges": [[int(s), int(e), bool(d)] for s, e, d in self.ranges], "training_mode": self.training_mode.name,
+               "numel": int(self.master.numel())}
+        if self.shard_optim:      # a sharded state file belongs to one rank of one world size
+            sig.update(world=int(self.world), rank=int(self.exchanger.rank), bucket_elems=int(self.bucket_elems))
+        return sig
+
+    def _state_file(self):
+        if self.shard_optim:
+            return f"optimizer_state.rank{self.exchanger.rank:05d}-of-{self.world:05d}.safetensors"
+        return "optimizer_state.safetensors"
 
     def save_state(self, path: str):
         """HF-Trainer-style `checkpoint-N` directory: the model (reference layout) + what a bit-exact resume needs beyond it:
@@ -587,10 +724,17 @@ class MultimodalTrainer:
         resume_from_checkpoint=...)).  No RNG state: the path has no dropout."""
         import json
         from safetensors.torch import save_file
-        self.save_model(path)
+        rank = self.exchanger.rank if self.shard_optim else (self.dist.get_rank(self.pg) if self.dist else 0)
+        if rank == 0:
+            self.save_model(path)                 # the parameters are replicated: one copy
+        else:
+            self._wait_optimizer()
+            os.makedirs(path, exist_ok=True)
+        if rank != 0 and not self.shard_optim:
+            return                                # replicated optimiser state: rank 0's files are everyone's
         save_file({"master": self.master.detach().cpu(), "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu()},
-                  os.path.join(path, "optimizer_state.safetensors"), metadata={"format": "pt"})
-        with open(os.path.join(path, "trainer_state.json"), "w") as f:
+                  os.path.join(path, self._state_file()), metadata={"format": "pt"})
+        with open(os.path.join(path, "trainer_state.json" if rank == 0 else f"trainer_state.rank{rank:05d}.json"), "w") as f:
             json.dump({"global_step": self.step_count, "micro_step": self._micro, "learning_rate": self.lr, "min_lr": self.min_lr,
                        "max_steps": self.max_steps, "warmup_steps": self.warmup, "weight_decay": self.wd, "betas": list(self.betas),
                        "eps": self.eps, "max_grad_norm": self.max_grad_norm, "gradient_accumulation_steps": self.accum,
@@ -602,18 +746,22 @@ class MultimodalTrainer:
         to the uninterrupted one."""
         import json
         from safetensors import safe_open
-        st = json.load(open(os.path.join(path, "trainer_state.json")))
+        rank = self.exchanger.rank if self.shard_optim else 0
+        st = json.load(open(os.path.join(path, "trainer_state.json" if rank == 0 else f"trainer_state.rank{rank:05d}.json")))
         if st["signature"] != self._state_signature():
             raise ValueError(f"{path}: optimizer state was saved for a different trainable set / training mode "
                              f"({st['signature']['training_mode']}, {st['signature']['numel']} elements)")
         self._wait_optimizer()
         if load_model:
             self.model.load_checkpoint_weights(path, strict=True)
-        with safe_open(os.path.join(path, "optimizer_state.safetensors"), framework="pt", device="cpu") as f:
+        with safe_open(os.path.join(path, self._state_file()), framework="pt", device="cpu") as f:
             self.master.copy_(f.get_tensor("master"))
             self.m.copy_(f.get_tensor("exp_avg"))
             self.v.copy_(f.get_tensor("exp_avg_sq"))
         with torch.no_grad():
+            if self.shard_optim:                  # my pieces from my master; the others' pieces came with the model weights
+                for a, b, _, off, _, _ in self.pieces:
+                    self.flat.data[a:b].copy_(self.master[off:off + b - a])
             for (s0, e0, _), off in zip(self.ranges, self.state_off):
                 self.flat.data[s0:e0].copy_(self.master[off:off + e0 - s0])       # bf16 parameters = round(master)
         self.step_count = int(st["global_step"])

@@ -29,10 +29,10 @@ def _build(tmp, dtype="float32"):
     return build_from_golden(meta, w, tmp, dtype), v, R
 
 
-def _rank(rank, world, port, tmp, q):
+def _rank(rank, world, port, tmp, q, shard="1"):
     try:
         import torch.distributed as dist
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MM_SHARD_OPTIM=shard)
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
@@ -40,7 +40,8 @@ def _rank(rank, world, port, tmp, q):
         model, v, R = _build(os.path.join(tmp, f"r{rank}"))
         tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=1e-3, betas=(0.9, 0.95), max_grad_norm=1.0,
                                bucket_mb=1)   # tiny buckets -> several buckets, launched from inside backward
-        tr.exchanger.buckets  # noqa
+        assert tr.shard_optim == (shard == "1")
+        n_state = int(tr.master.numel())
         cases = [("right", "interleaved4"), ("left", "textonly"), ("interleaved4", "right")]
         early = []
         for step in cases:
@@ -49,28 +50,44 @@ def _rank(rank, world, port, tmp, q):
         tr.synchronize()
         torch.cuda.synchronize()
         sd = {k: p.detach().float().cpu().numpy() for k, p in model.named_parameters()}   # by value through the queue
-        q.put((rank, "ok", sd if rank == 0 else None, early, len(tr.exchanger.buckets)))
+        q.put((rank, "ok", sd, early, len(tr.exchanger.buckets), n_state))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
         import traceback
-        q.put((rank, "fail: " + traceback.format_exc()[-1500:], None, None, None))
+        q.put((rank, "fail: " + traceback.format_exc()[-1500:], None, None, None, None))
 
 
-def test_dp2_equals_grad_accumulation(tmp_path):
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+def _run_dp2(tmp, shard):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, os.path.join(str(tmp), "shard" + shard), q, shard)) for r in range(2)]
     for p in procs:
         p.start()
     out = [q.get(timeout=150) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert all(o[1] == "ok" for o in out), [o[1] for o in out]
-    r0 = [o for o in out if o[0] == 0][0]
+    return sorted(out, key=lambda o: o[0])
+
+
+def test_dp2_equals_grad_accumulation(tmp_path):
+    """DP2 (sharded optimiser step: reduce-scatter, AdamW on each rank's half of the state, all-gather of the parameters -- the
+    default for world > 1; and the replicated step, MM_SHARD_OPTIM=0) == one process with gradient accumulation over the same
+    micro-batches; the two ranks of a run end with bit-identical parameters; a rank of the sharded run holds half the state."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sharded = _run_dp2(tmp_path, "1")
+    repl = _run_dp2(tmp_path, "0")
+    for run in (sharded, repl):
+        for k in run[0][2]:
+            assert (run[0][2][k] == run[1][2][k]).all(), k                      # rank 0 == rank 1, bit for bit
+    assert sharded[0][5] + sharded[1][5] <= repl[0][5] + 16 * sharded[0][4] and sharded[0][5] < 0.6 * repl[0][5]
+    for k in repl[0][2]:
+        a, b = torch.from_numpy(sharded[0][2][k]), torch.from_numpy(repl[0][2][k])
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 1e-5, k             # differ only by the summation order of the norm
+    r0 = sharded[0]
     dp_params, early, nb = r0[2], r0[3], r0[4]
     assert nb > 1
     assert early[0] == 0 and early[1] > 0 and early[2] > 0, early     # step 1 learns write counts; later steps overlap
@@ -118,12 +135,13 @@ def _abi_rank(port, tmp, q):
                 res[(algo, str(dtype))] = bool(torch.equal(y, ref)) and bool(torch.equal(z, ref[:1_000_000]))
             c.close()
         params = {}
-        for mode in ("torch-none", "abi", "abi-rsag"):
+        for mode in ("torch-none", "abi", "abi-rsag", "abi-sharded"):
             if mode == "torch-none":
                 os.environ.pop("MM_COMM", None)
                 os.environ.pop("MM_FORCE_EXCHANGE", None)
-            else:
-                os.environ.update(MM_COMM=mode, MM_FORCE_EXCHANGE="1")
+            else:      # abi-sharded: the sharded optimiser step's reduce-scatter / all-gather through the communicator
+                os.environ.update(MM_COMM="abi" if mode == "abi-sharded" else mode, MM_FORCE_EXCHANGE="1",
+                                  MM_SHARD_OPTIM="1" if mode == "abi-sharded" else "0")
             model, v, R = _build(os.path.join(tmp, mode), "bfloat16")
             tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=1e-3, betas=(0.9, 0.95), max_grad_norm=1.0,
                                    bucket_mb=1)
@@ -164,3 +182,8 @@ def test_c_abi_communicator_single_rank(tmp_path):
         assert early[0] == 0 and early[1] > 0 and early[2] > 0, early
         for k in base:
             assert (got[k] == base[k]).all(), (mode, k)
+    got, early, kind = params["abi-sharded"]        # same update up to the summation order of the gradient norm (bf16 parameters)
+    assert kind == "RcclComm" and early[1] > 0
+    for k in base:
+        a, b = torch.from_numpy(got[k]), torch.from_numpy(base[k])
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 2e-3, k

@@ -83,6 +83,71 @@ def test_bucketed_allreduce_two_ranks():
     assert all(o[1] == "ok" for o in out), out
 
 
+def _worker_sharded(rank, world, port, q):
+    """Sharded exchange (reduce-scatter + all-gather) on CPU tensors: the halves the trainer's sharded optimiser step slots between."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1000
+        ranges = [(0, 601), (608, 1000)]                         # two trainable ranges (decay / no decay), ragged ends
+        segs = [(1, 0, 256), (2, 256, 601), (3, 608, 1000)]
+        grad = torch.zeros(n)
+        ex = GradExchanger(grad, ranges, segs, bucket_elems=300, dist=dist, sharded=True)
+        assert [(b.start, b.end) for b in ex.buckets] == [(0, 300), (300, 600), (600, 601), (608, 908), (908, 1000)]
+        assert [b.q for b in ex.buckets] == [144, 144, 0, 144, 40]   # multiples of 8; bucket (600, 601) is all tail
+        params = torch.arange(n, dtype=torch.float32).clone()    # replicated "parameters"
+        ref = params.clone()
+        lr = 0.5
+        for step in range(3):
+            full = [torch.sin(torch.arange(n, dtype=torch.float32) * (r + 1) + step) for r in range(world)]
+            grad.copy_(full[rank])
+            ex.begin_step(True)
+            for k in (3, 2, 1):
+                ex.on_ready(k)
+            ex.finish_step()
+            tot = sum(full)
+            own = torch.zeros(n, dtype=torch.bool)
+            for bk in ex.buckets:
+                (s, e), (ts, te) = bk.shard(rank, world)
+                assert torch.allclose(grad[s:e], tot[s:e]) and torch.allclose(grad[ts:te], tot[ts:te]), (rank, step, bk.start)
+                own[s:e] = True
+                own[ts:te] = True
+                params[s:e] -= lr * grad[s:e]                    # "optimiser": my share + the tail every rank keeps
+                params[ts:te] -= lr * grad[ts:te]
+            works = [ex.all_gather_params(params, bk) for bk in ex.buckets]
+            for w in works:
+                w.wait()
+            for a, b in ranges:
+                ref[a:b] -= lr * tot[a:b]
+            assert torch.allclose(params, ref, atol=1e-6), (rank, step, float((params - ref).abs().max()))
+            assert torch.equal(params[601:608], torch.arange(601, 608, dtype=torch.float32))          # outside the ranges: untouched
+        # every element of a range is owned by exactly one rank, or by all of them (tails)
+        cnt = own.float()
+        dist.all_reduce(cnt)
+        for a, b in ranges:
+            assert set(cnt[a:b].tolist()) <= {1.0, float(world)}
+        q.put((rank, "ok", params.tolist()))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, f"fail: {traceback.format_exc()[-800:]}", None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_exchange_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(o[1] == "ok" for o in out), out
+    assert out[0][2] == out[1][2]                                # the two ranks end with bit-identical parameters
+
+
 def test_single_process_is_a_noop():
     grad = torch.ones(100)
     ex = GradExchanger(grad, [(0, 100)], [(1, 0, 100)], 64, dist=None)
