@@ -128,12 +128,24 @@ def measure_gemm_roofline(trainer, batch):
             rec.append((e0, e1, 2.0 * M * I * H, ("NN+swiglu_bwd", M, I, H)))
         return out
 
-    K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd = timed, timed_sf, timed_sb
+    orig_act = K.linear_act_fwd
+
+    def timed_act(x2d, w, bias, act, residual=None):  # Linear + GELU in one launch (ViT fc1, projector): mm_gemm_act_fwd
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_act(x2d, w, bias, act, residual)
+        e1.record()
+        if out is not None:
+            M, Kd = x2d.shape
+            rec.append((e0, e1, 2.0 * M * w.shape[0] * Kd, ("NT+act", M, w.shape[0], Kd)))
+        return out
+
+    K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd, K.linear_act_fwd = timed, timed_sf, timed_sb, timed_act
     try:
         trainer.training_step(batch)
         torch.cuda.synchronize()
     finally:
-        K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd = orig, orig_sf, orig_sb
+        K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd, K.linear_act_fwd = orig, orig_sf, orig_sb, orig_act
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
     tot_fl = sum(f for _, _, f, _ in rec)
     alg_bytes = sum(2.0 * (M * Kd + N * Kd + M * N) for _, _, _, (_, M, N, Kd) in rec)      # A, B, C once, bf16
@@ -154,19 +166,28 @@ def kernel_source_sha():
 
 
 def pmc_traffic():
-    """HBM bytes per GEMM launch from the PMC passes of this same command (tools/profile_round.sh ->
-    profiles/r02_pmc_traffic.json): counters cannot be collected from inside the timed process, so `traffic` is the figure of
-    those separate rocprofv3 --pmc runs.  The file records the kernel-source hash it was measured on; a figure taken on
-    DIFFERENT kernels is not printed (traffic = null, with the reason)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except Exception:
-        return None, "no profiles/r02_pmc_traffic.json"
-    if d.get("kernel_source_sha") != kernel_source_sha():
-        return None, f"profiles/r02_pmc_traffic.json was measured on other kernel sources ({d.get('kernel_source_sha')}): re-run tools/profile_round.sh"
-    return d, None
+    """HBM bytes per GEMM launch from the PMC passes of this same command (tools/profile_round.sh -> tools/publish_profile.py ->
+    profiles/rNN_pmc_traffic.json, the newest round first): counters cannot be collected from inside the timed process, so
+    `traffic` is the figure of those separate rocprofv3 --pmc runs.  The file records the kernel-source hash it was measured on
+    (written on the GPU box by tools/pmc_summary.py, never by hand); a figure taken on DIFFERENT kernels is not printed
+    (traffic = null, with the reason)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True)
+    if not files:
+        return None, "no profiles/rNN_pmc_traffic.json"
+    sha, why = kernel_source_sha(), None
+    for path in files:
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        if d.get("kernel_source_sha") == sha:
+            d["file"] = "profiles/" + os.path.basename(path)
+            return d, None
+        why = why or (f"profiles/{os.path.basename(path)} was measured on other kernel sources ({d.get('kernel_source_sha')}, now {sha}): "
+                      "re-run tools/profile_round.sh")
+    return None, why
 
 
 def cpu_model_name():
@@ -333,6 +354,8 @@ def main():
     ap.add_argument("--mode", default="FULL", choices=["FULL", "ALIGNMENT", "END2END", "LM_ONLY"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--padded", action="store_true", help="right-padded batch, lengths U[S/2, S] (SURVEY 8d: the key-mask path); "
+                                                          "not the headline configuration")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal on CPU/gloo: no model, no kernels, no measurement")
     args = ap.parse_args()
 
@@ -387,6 +410,14 @@ def main():
     # contains the per-step list -> stack -> H2D of image_modality.py:131-132 and the mask handling, not a resident tensor
     from multimeditron_amd.train.prefetch import DevicePrefetcher
     host_batch, _ = synthetic_batch(B, S, n_img, P, vocab, special, 1234 + rank, "cpu", vis["image_size"], collator_form=True)
+    if args.padded:       # SURVEY 8d's mask variant: right padding, lengths U[S/2, S] (the image span sits in the first half)
+        gpad = torch.Generator().manual_seed(4321 + rank)
+        lo = max(S // 2, int(host_batch["processed_multimodal_inputs"]["token_range"]["image"].max()) + 2)     # never cut an image span
+        lens = torch.randint(lo, S + 1, (B,), generator=gpad)
+        lens[0] = S
+        keep = torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)
+        host_batch["attention_mask"] = keep.long()
+        host_batch["labels"] = torch.where(keep, host_batch["labels"], torch.full_like(host_batch["labels"], -100))
 
     def endless():
         while True:
@@ -419,7 +450,10 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "images_per_sample": n_img,
-                      "training_mode": args.mode, "optimizer": "AdamW every step (fused, fp32 master+m+v)", "parallelism": f"dp{world}",
+                      "training_mode": args.mode,
+                      "optimizer": "AdamW every step (fused, fp32 master+m+v" + (f"; state sharded over the {world} ranks: reduce-scatter, "
+                                   "update, all-gather)" if trainer.shard_optim else ")"), "parallelism": f"dp{world}",
+                      **({"padding": "right-padded, lengths U[S/2, S] (key-mask path); tokens counted as S per sample"} if args.padded else {}),
                       "final_loss": round(float(loss), 4),
                       "input_staging": "collator-form host batch (all-ones attention_mask, list of per-image tensors) staged per step by "
                                        "train/prefetch.py DevicePrefetcher (pinned, side stream)",
@@ -443,7 +477,7 @@ def main():
             pt, why = pmc_traffic()
             if pt is not None and args.workload == "llama31_8b_vitl14_s2048_b4" and args.mode == "FULL":
                 roof["traffic"] = round(pt["bytes_per_launch"])       # HBM bytes per launch, same averaging as `achieved`
-                roof["traffic_source"] = "profiles/r02_pmc_traffic.json: " + pt["method"]
+                roof["traffic_source"] = pt["file"] + ": " + pt["method"]
             else:
                 roof["traffic_source"] = why or "PMC passes exist for the headline workload in FULL mode only"
             if fps is not None:

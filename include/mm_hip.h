@@ -63,6 +63,13 @@ int mm_attn_set_issue_waves(int v);
 int mm_gemm(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
             void* C, int ldc, const void* bias, const void* residual, int ldr, int epilogue, void* stream);
 
+/* Fused q|k|v projection + RoPE: qkv[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) with the first rope_cols columns -- heads of width
+ * head_dim = 128 -- rotated in the GEMM's epilogue by the per-token tables cos_t / sin_t [M, head_dim/2] f32 of mm_rope_table
+ * (HF:llama:232-244 q/k/v_proj followed by apply_rotary_pos_emb :113-160); the remaining columns (v) are stored unrotated.
+ * Bit-identical to mm_gemm + mm_rope_apply, one pass over q|k less.  MM_BF16; MM_ERR_UNSUPPORTED for other head widths, N or
+ * rope_cols not multiples of 128, or M < 256 (use the two launches).                                                    */
+int mm_gemm_rope_fwd(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* bias, void* QKV,
+                     int ldqkv, int rope_cols, int head_dim, const float* cos_t, const float* sin_t, void* stream);
 /* SwiGLU MLP front half in ONE GEMM: replaces `act_fn(gate_proj(x)) * up_proj(x)` (HF:llama:163-176) = two F.linear + silu +
  * mul.  Wgu = the fused [2I, K] gate|up weight (gate rows first); GU [M, 2I] receives the bf16 pre-activations (what the two
  * linears would store; kept for backward), ACT [M, I] = bf16(bf16(silu(gate)) * up): bit-identical to mm_gemm + mm_swiglu_fwd.

@@ -73,6 +73,12 @@ __device__ __forceinline__ float block_max_256(float x, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// RoPE of one (x[d], x[d + D/2]) pair: out_lo = x_lo cos - x_hi sin, out_hi = x_hi cos + x_lo sin (HF:llama apply_rotary_pos_emb with
+// rotate_half), written with ONE explicit rounding sequence (a product, then a fused multiply-add) so that the stand-alone kernels
+// (mm_rope_apply, mm_rope_append) and the GEMM epilogue that fuses the rotation (mm_gemm_rope_fwd) give the same bits.
+__device__ __forceinline__ float rope_lo(float lo, float hi, float c, float s) { return __builtin_fmaf(lo, c, -__fmul_rn(hi, s)); }
+__device__ __forceinline__ float rope_hi(float lo, float hi, float c, float s) { return __builtin_fmaf(hi, c, __fmul_rn(lo, s)); }
+
 // ---- LDS-DMA (buffer_load_dwordx4 ... lds) issued from inline asm -----------------------------------------------
 // hipcc's waitcnt pass does not see these, so it neither drains them in front of ds_read_b64_tr_b16 nor counts them:
 // completion is tracked by hand (s_waitcnt vmcnt(N) + s_barrier before any wave reads the bytes).  The descriptor is

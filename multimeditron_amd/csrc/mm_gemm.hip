@@ -47,6 +47,10 @@ struct GemmArgs {
   void* C2; int ldc2;
   const void* aux; int ldaux;   // MM_EPI_SWIGLU_BWD: the saved pre-activations [M, 2I]
   int pipe;                     // pipelined epilogue (mm_set_option "gemm_epi_pipe", default 1)
+  // fused RoPE (mm_gemm_rope_fwd): the first rope_cols output columns are heads of width 128 that the epilogue rotates with the
+  // per-token tables rope_cos / rope_sin [M, 64] f32 (0 = no rotation).  The B tile's rows are gathered so that a lane owns
+  // columns d and d + 64 of a head (rope_row).
+  const float* rope_cos; const float* rope_sin; int rope_cols;
 };
 constexpr int MM_EPI_SWIGLU_BWD = 1 << 20;   // internal epilogue flag (mm_gemm_swiglu_bwd), not part of the ABI enum
 
@@ -592,6 +596,78 @@ __device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&
   }
 }
 
+// epilogue of the fused q|k|v projection + RoPE (mm_gemm_rope_fwd): acc[i][j] (j < 2) = columns d .. d+3 of a 128-wide head,
+// acc[i][j + 2] = columns d + 64 .. (the B tile's rows were gathered that way, rope_row).  The projection output is rounded to
+// bf16 first, exactly what the unfused GEMM stores, then rotated with the arithmetic of rope_apply_kernel (rope_lo / rope_hi):
+// bit-identical to mm_gemm + mm_rope_apply, one read-modify-write pass over q|k less.  Tiles at or beyond rope_cols (the v heads)
+// are stored unrotated.  Table rows and the rows of C go through the buffer range check (descriptors anchored at the wave's
+// first row); the loads of row block i + 1 are requested before block i is rotated and stored.
+template <int MREP, int NREP>
+__device__ __forceinline__ void gemm_epilogue_rope(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int n0, int wn) {
+  static_assert(NREP == 4, "a wave owns 64 columns: two 16-column tiles of d and their partners d + 64");
+  const int l = threadIdx.x & 63;
+  mw = __builtin_amdgcn_readfirstlane(mw);
+  const int hb = __builtin_amdgcn_readfirstlane(n0 + (wn >> 1) * 128);          // first column of the wave's head
+  const int dlo = __builtin_amdgcn_readfirstlane((wn & 1) * 32);
+  const bool rot = n0 < g.rope_cols;
+  const int rows = g.M - mw;
+  auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)rows * g.ldc * 2);
+  auto rcs = make_rsrc(g.rope_cos + (int64_t)mw * 64, rot ? (int64_t)rows * 64 * 4 : 0);
+  auto rsn = make_rsrc(g.rope_sin + (int64_t)mw * 64, rot ? (int64_t)rows * 64 * 4 : 0);
+  const bool has_bias = (g.epi & MM_EPI_BIAS) != 0;
+  const bool head_ok = hb < g.N;                                                 // N is a multiple of 128: a head is whole or absent
+  float b1[2][4], b2[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int d = dlo + j * 16 + 4 * (l >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { b1[j][r] = 0.f; b2[j][r] = 0.f; }
+    if (has_bias && head_ok) {
+      const bf16x4 v1 = *(const bf16x4*)((const bf16*)g.bias + hb + d), v2 = *(const bf16x4*)((const bf16*)g.bias + hb + d + 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { b1[j][r] = (float)v1[r]; b2[j][r] = (float)v2[r]; }
+    }
+  }
+  u32x4 cb[2][2], sb[2][2];
+  auto request = [&](int i, int s) {
+    const unsigned row = (unsigned)(i * 16 + (l & 15)) * 256u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned o = row + (unsigned)(dlo + j * 16 + 4 * (l >> 4)) * 4u;
+      cb[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rcs, o, 0, 0);
+      sb[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rsn, o, 0, 0);
+    }
+  };
+  if (rot) request(0, 0);
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    if (rot && i + 1 < MREP) request(i + 1, (i + 1) & 1);
+    const unsigned rowc = (unsigned)((i * 16 + (l & 15)) * g.ldc) * 2u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int d = dlo + j * 16 + 4 * (l >> 4);
+      bf16x4 o1, o2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o1[r] = (bf16)(acc[i][j][r] + b1[j][r]);
+        o2[r] = (bf16)(acc[i][j + 2][r] + b2[j][r]);
+      }
+      if (rot) {
+        const f32x4 c4 = __builtin_bit_cast(f32x4, cb[i & 1][j]), s4 = __builtin_bit_cast(f32x4, sb[i & 1][j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = (float)o1[r], b = (float)o2[r];
+          o1[r] = (bf16)rope_lo(a, b, c4[r], s4[r]);
+          o2[r] = (bf16)rope_hi(a, b, c4[r], s4[r]);
+        }
+      }
+      const unsigned o = head_ok ? rowc + (unsigned)(hb + d) * 2u : EPI_OOB;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o1), rc, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), rc, o == EPI_OOB ? EPI_OOB : o + 128u, 0, 0);
+    }
+  }
+}
+
 // N LDS-DMA pieces of one operand tile in ONE asm statement: M0 saved/restored once, one hazard pad for the
 // freshly written descriptor SGPRs (the compiler pads nothing inside an asm string).
 template <int N, int STEP>
@@ -646,6 +722,15 @@ __device__ __forceinline__ int swiglu_row(int r, int I) {
   return (r >> 6) * 32 + ((r >> 4) & 1) * 16 + (r & 15) + ((r >> 5) & 1) * I;
 }
 
+// fused RoPE (head width 128): local row r of the 256-row B tile (2 heads; wave wn = r >> 6 owns 64 of them as 4 n-tiles of 16)
+// -> row of the [N, K] weight relative to the tile's first row: n-tiles 0,1 of a wave hold d = (wn & 1) * 32 + 0..31 of head
+// wn >> 1, n-tiles 2,3 the partners d + 64, so acc[i][j] and acc[i][j + 2] of a lane are the two halves rotate_half pairs up
+__device__ __forceinline__ int rope_row(int r) {
+  return (r >> 7) * 128 + ((r >> 6) & 1) * 32 + ((r >> 4) & 1) * 16 + (r & 15) + ((r >> 5) & 1) * 64;
+}
+// B-row gather of the fused epilogues: mode > 0 = SwiGLU with I = mode, mode < 0 = RoPE, 0 = none
+__device__ __forceinline__ int gather_row(int r, int mode) { return mode > 0 ? swiglu_row(r, mode) : (mode < 0 ? rope_row(r) : r); }
+
 // NW = number of waves that issue the tile's DMA (8 = all; 4 = waves 0-3 only, which staggers the two waves of a SIMD)
 template <bool KC, int XR, int NW>
 __device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld, int k0, int Ktot, int swi_I = 0) {
@@ -663,7 +748,7 @@ __device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld,
       if constexpr (KC) {                 // piece = 8 rows x 128 B
         const int row = pc * 8 + (l >> 3);
         const int kc = (l & 7) ^ kc_swz(row);           // source chunk whose home is slot (l&7) of this row
-        const int srow = swi_I ? swiglu_row(row, swi_I) : row;
+        const int srow = gather_row(row, swi_I);
         unsigned off = (unsigned)(srow * ld + k0 + kc * 8) * 2u;
         if ((k0 + kc * 8) >= Ktot) off = 0xFFFFFFFFu;
         offs[i] = off;
@@ -696,7 +781,7 @@ __device__ __forceinline__ void dma_offsets(unsigned (&offs)[XR / (8 * NW)], int
     if constexpr (KC) {
       const int row = pc * 8 + (l >> 3);
       const int kc = (l & 7) ^ kc_swz(row);
-      offs[i] = (unsigned)((swi_I ? swiglu_row(row, swi_I) : row) * ld + kc * 8) * 2u;
+      offs[i] = (unsigned)(gather_row(row, swi_I) * ld + kc * 8) * 2u;
     } else {
       constexpr int SPR = XR / 8, RPP = 64 / SPR;
       const int k = pc * RPP + l / SPR;
@@ -795,8 +880,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
   // (mm_gemm_swiglu_fwd, NT 256x256).  With the rare epilogues inlined behind runtime branches every GEMM of the step ran
   // 1.6 % slower than the round-1 library on the same box (tools/gemm_bench.py, 15 shapes); with them in their own
   // instantiations the plain kernel is the round-1 kernel again.
-  const int swi = (EK == 3) ? g.swi_I : 0;                               // fused SwiGLU: a tile = 128 features (gate + up)
-  const int nstep = swi ? BN_ / 2 : BN_;
+  const int swi = (EK == 3) ? g.swi_I : (EK == 4 ? -1 : 0);              // B-row gather: fused SwiGLU (a tile = 128 features, gate + up) / RoPE
+  const int nstep = swi > 0 ? BN_ / 2 : BN_;
   int m0 = pm * BM_, n0 = pn * nstep;
   SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
   SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
@@ -889,7 +974,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
         }
       }
     }
-    if constexpr (EK == 3) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
+    if constexpr (EK == 4) gemm_epilogue_rope<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0, wn);
+    else if constexpr (EK == 3) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
     else if constexpr (EK == 2) gemm_epilogue_ek2<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     else if constexpr (EK == 0) gemm_epilogue_ek0<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     else gemm_epilogue_plain<MREP, NREP, (BM_ * BN_ <= 128 * 128) && EK == 1, EK == 1>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
@@ -900,7 +986,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
     rb = nrb;
   }
   // ---- the half-tile round (256 x BN/2): same A tile and image, B tile of half the rows; not chained to the stream above
-  if constexpr (BM_ == 256 && BN_ == 256 && (NREP % 2) == 0) {
+  if constexpr (BM_ == 256 && BN_ == 256 && (NREP % 2) == 0 && EK != 4) {
     if (g.tail > 0 && (int)blockIdx.x < 2 * g.tail) {
       constexpr int BNH = BN_ / 2, NREPH = NREP / 2, HM = MREP / 2;
       constexpr bool INVH = INV && (BNH / (8 * ISSUE_WAVES)) % 4 == 0;
@@ -1247,6 +1333,27 @@ extern "C" int mm_gemm_swiglu_fwd(int dtype, int M, int I, int K, const void* X,
   return gemm_launch(g, dtype, MM_GEMM_NT, (hipStream_t)stream);
 }
 
+// qkv = x W^T (+ b) for the fused [q | k | v] projection with RoPE applied to the q and k heads in the GEMM's epilogue
+// (HF:models/llama/modeling_llama.py:232-244 q/k/v_proj, then apply_rotary_pos_emb :113-160): rope_cols = (Hq + Hkv) * 128 leading
+// columns are 128-wide heads rotated with the per-token tables cos_t / sin_t [M, 64] f32 (mm_rope_table); the rest (v) is stored
+// as is.  Bit-identical to mm_gemm + mm_rope_apply.  MM_ERR_UNSUPPORTED when the shape does not take the 256x256 LDS-DMA tile or the
+// head width is not 128 (the caller then uses the two launches).
+extern "C" int mm_gemm_rope_fwd(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* bias, void* QKV,
+                                int ldqkv, int rope_cols, int head_dim, const float* cos_t, const float* sin_t, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || rope_cols < 0 || rope_cols > N) return MM_ERR_ARG;
+  if (M == 0) return MM_OK;
+  if (!X || !W || !QKV || !cos_t || !sin_t) return MM_ERR_ARG;
+  if (dtype != MM_BF16 || head_dim != 128 || (N & 127) || (rope_cols & 127) || M < 256) return MM_ERR_UNSUPPORTED;
+  if ((ldqkv & 3) || (((uintptr_t)QKV) & 7) || (((uintptr_t)cos_t) & 15) || (((uintptr_t)sin_t) & 15) || (bias && (((uintptr_t)bias) & 7)))
+    return MM_ERR_ALIGN;
+  if ((int64_t)N * ldw * 2 >= 0xFFFFFFFFll) return MM_ERR_UNSUPPORTED;
+  GemmArgs g{M, N, K, X, ldx, W, ldw, QKV, ldqkv, bias, nullptr, 0, bias ? MM_EPI_BIAS : 0, 0, 0, 0, 0, nullptr, 0, nullptr, 0};
+  g.rope_cos = cos_t;
+  g.rope_sin = sin_t;
+  g.rope_cols = rope_cols ? rope_cols : -1;          // -1: the fused kernel with nothing to rotate (keeps the dispatch below simple)
+  return gemm_launch(g, dtype, MM_GEMM_NT, (hipStream_t)stream);
+}
+
 // y = act(x W^T + b) (+ residual) with the bf16 pre-activation kept in PRE for backward: the forward of a Linear + GELU in ONE
 // launch where training used three (GEMM, activation, add).  Roundings as in that form: bit-identical results.
 extern "C" int mm_gemm_act_fwd(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* bias,
@@ -1326,7 +1433,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'b' ? 3 : 2));
     }();
     const int forced = g_opt_kernel ? g_opt_kernel : forced_env;
-    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 && !g.swi_I &&
+    if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 && !g.swi_I && !g.rope_cols &&
         (int64_t)16 * lda * 2 < 0xFFFFFFFFll && (int64_t)16 * ldb * 2 < 0xFFFFFFFFll) {   // decode: stream W once
       dim3 grid((unsigned)((N + 15) / 16)), block(512);
       hipLaunchKernelGGL(gemm_skinny_kernel, grid, block, 0, s, g);
@@ -1342,8 +1449,10 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
     const int64_t tiles_256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     int variant = 0;   // 0 = v1 (128x128 register staged); DMA tiles: 1 = 256x128, 2 = 256x256, 3 = 128x128, 4 = 64x128, 5 = 64x64
     const bool keep_pre = g.C2 != nullptr && !g.swi_I;      // mm_gemm_act_fwd: compiled into the small-tile DMA kernels only
-    if (g.swi_I) variant = 2;                 // the fused gate|up tile is defined on the 256x256 kernel only
-    else if (keep_pre) {
+    if (g.swi_I || g.rope_cols) {             // the fused gate|up / RoPE tiles are defined on the 256x256 kernel only
+      if (!fits32) return MM_ERR_UNSUPPORTED;
+      variant = 2;
+    } else if (keep_pre) {
       if (!fits32 || forced == 1) return MM_ERR_UNSUPPORTED;
       variant = (forced >= 4 && forced <= 6) ? forced - 1 : small_variant(M, N, K);
       if (variant < 3) variant = 3;           // a problem that would take a 256-wide tile: 128x128 (the caller may prefer the separate launches)
@@ -1363,7 +1472,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
       // persistent: one resident workgroup per CU walks the tiles; otherwise one tile each
       int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
-      if (g_opt_persist && g_opt_tail && variant == 2 && !g.swi_I) {       // wave quantisation: see the kernel
+      if (g_opt_persist && g_opt_tail && variant == 2 && !g.swi_I && !g.rope_cols) {       // wave quantisation: see the kernel
         const int64_t rem = nwg % ncu;
         if (rem > 0 && 2 * rem <= ncu) {
           g.tail = (int)rem;
@@ -1387,7 +1496,11 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
     else MM_LAUNCH_ONE(AKC, BKC, 256, 256, 2, 2, 8, EK);                                                                 \
   } while (0)
       // epilogue kind = kernel instantiation: the SwiGLU ones exist for the layout their entry point uses only
-      if (g.swi_I) {                                                      // mm_gemm_swiglu_fwd: NT, 256x256 (variant 2 above)
+      if (g.rope_cols) {                                                  // mm_gemm_rope_fwd: NT, 256x256
+        if (layout != MM_GEMM_NT) return MM_ERR_ARG;
+        if (g_opt_issue_waves == 4) MM_LAUNCH_ONE(true, true, 256, 256, 2, 2, 4, 4);
+        else MM_LAUNCH_ONE(true, true, 256, 256, 2, 2, 8, 4);
+      } else if (g.swi_I) {                                               // mm_gemm_swiglu_fwd: NT, 256x256 (variant 2 above)
         if (layout != MM_GEMM_NT) return MM_ERR_ARG;
         if (g_opt_issue_waves == 4) MM_LAUNCH_ONE(true, true, 256, 256, 2, 2, 4, 3);
         else MM_LAUNCH_ONE(true, true, 256, 256, 2, 2, 8, 3);

@@ -288,8 +288,8 @@ __global__ void rope_apply_kernel(T* x, int Tn, int nheads, int D, int ld, const
 #pragma unroll
   for (int k = 0; k < VN; ++k) {
     const float cc = c[k], ss = inverse ? -s[k] : s[k];
-    oa.set(k, a.get(k) * cc - b.get(k) * ss);
-    ob.set(k, b.get(k) * cc + a.get(k) * ss);
+    oa.set(k, rope_lo(a.get(k), b.get(k), cc, ss));
+    ob.set(k, rope_hi(a.get(k), b.get(k), cc, ss));
   }
   *(Vec16<T>*)p = oa;
   *(Vec16<T>*)(p + half) = ob;
@@ -315,8 +315,8 @@ __global__ void rope_append_kernel(T* x, int Tn, int Hq, int Hkv, int D, int ld,
     const float* s = sn + (int64_t)t * half + jc * VN;
 #pragma unroll
     for (int k = 0; k < VN; ++k) {
-      oa.set(k, a.get(k) * c[k] - b.get(k) * s[k]);
-      ob.set(k, b.get(k) * c[k] + a.get(k) * s[k]);
+      oa.set(k, rope_lo(a.get(k), b.get(k), c[k], s[k]));
+      ob.set(k, rope_hi(a.get(k), b.get(k), c[k], s[k]));
     }
     *(Vec16<T>*)p = oa;
     *(Vec16<T>*)(p + half) = ob;

@@ -118,8 +118,10 @@ def flush_deferred_wgrads():
         from ._lib import get_option, lib
         main, side = torch.cuda.current_stream(), d["stream"]
         side.wait_stream(main)
+        import os
         persist = get_option("gemm_persist")         # restore what the trainer / the user had set, not a constant
-        lib().mm_set_option(b"gemm_persist", 0)      # one tile per workgroup: shares the chip with the other stream's kernels
+        # one tile per workgroup: shares the chip with the other stream's kernels (MM_DEFER_PERSIST=1: keep the persistent grid)
+        lib().mm_set_option(b"gemm_persist", 1 if os.environ.get("MM_DEFER_PERSIST", "0") == "1" else 0)
         try:
             with torch.cuda.stream(side):
                 for dy, x, wg in d["items"]:
@@ -344,6 +346,60 @@ class RopeAttentionFn(torch.autograd.Function):
 
 def rope_attention(qkv, cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale):
     return RopeAttentionFn.apply(qkv, cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale)
+
+
+class QKVRopeAttentionFn(torch.autograd.Function):
+    """The decoder's attention front half as ONE node: fused q|k|v projection with RoPE in its epilogue (mm_gemm_rope_fwd; the
+    projection + mm_rope_apply when a shape does not qualify: same bits), then flash attention.  h [T, H] -> out [T, Hq*D].
+    Backward = attention backward, inverse RoPE on d(q|k) in place, then the projection's wgrad / bias / dgrad (LinearFn's)."""
+
+    @staticmethod
+    def forward(ctx, h, dummy, wg: ParamGroup, bg: Optional[ParamGroup], cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale):
+        w = wg.tensor()
+        b = bg.tensor() if bg is not None else None
+        W = (Hq + 2 * Hkv) * D
+        qkv = K.gemm_rope_fwd(h, w, b, (Hq + Hkv) * D, D, cos, sin) if cos is not None else None
+        if qkv is None:
+            qkv = K.linear_fwd(h, w, bias=b)
+            if cos is not None:
+                K.rope_apply_(qkv, B * S, Hq + Hkv, D, W, cos, sin)
+        q = qkv[:, : Hq * D].view(B, S, Hq, D)
+        k = qkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D)
+        v = qkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+        out, lse = K.attn_fwd(q, k, v, key_mask, causal, scale)
+        ctx.dims = (B, S, Hq, Hkv, D, causal, scale)
+        ctx.wg, ctx.bg = wg, bg
+        ctx.save_for_backward(h, qkv, out, lse, cos, sin, key_mask)
+        return out.view(B * S, Hq * D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, qkv, out, lse, cos, sin, key_mask = ctx.saved_tensors
+        B, S, Hq, Hkv, D, causal, scale = ctx.dims
+        wg, bg = ctx.wg, ctx.bg
+        W = (Hq + 2 * Hkv) * D
+        q = qkv[:, : Hq * D].view(B, S, Hq, D)
+        k = qkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D)
+        v = qkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+        dqkv = torch.zeros_like(qkv) if qkv.dtype == torch.float32 else torch.empty_like(qkv)
+        dq = dqkv[:, : Hq * D].view(B, S, Hq, D)
+        dk = dqkv[:, Hq * D:(Hq + Hkv) * D].view(B, S, Hkv, D)
+        dv = dqkv[:, (Hq + Hkv) * D:].view(B, S, Hkv, D)
+        K.attn_bwd(q, k, v, out, dout.contiguous().view(B, S, Hq, D), lse, key_mask, causal, scale, dq, dk, dv)
+        if cos is not None:
+            K.rope_apply_(dqkv, B * S, Hq + Hkv, D, W, cos, sin, inverse=True)
+        if bg is not None and bg.requires_grad:
+            g, acc = bg.grad_target()
+            K.colsum(dqkv, g, acc)
+            bg.ready()
+        _wgrad(dqkv, h, wg)
+        dh = K.linear_dgrad(dqkv, wg.tensor()) if ctx.needs_input_grad[0] else None
+        return (dh,) + (None,) * 13
+
+
+def qkv_rope_attention(h, wg, bg, cos, sin, key_mask, B, S, Hq, Hkv, D, causal, scale, dummy=None):
+    return QKVRopeAttentionFn.apply(h, dummy, as_group(wg), as_group(bg) if bg is not None else None, cos, sin, key_mask, B, S, Hq, Hkv, D,
+                                    causal, scale)
 
 
 class HeadPadFn(torch.autograd.Function):

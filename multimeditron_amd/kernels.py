@@ -136,6 +136,24 @@ def gemm_swiglu_fwd(x2d, wgu, I):
     return gu, act
 
 
+def _fused_rope():         # A/B switch (tools/step_ab.py): MM_FUSED_ROPE=0 -> GEMM + separate RoPE kernel
+    return _os.environ.get("MM_FUSED_ROPE", "1") != "0"
+
+
+def gemm_rope_fwd(x2d, w, bias, rope_cols, D, cos, sin):
+    """qkv [M, N] = x @ w^T (+ bias) with RoPE on the first rope_cols columns, in one launch; None when the shape must take the
+    two-launch form (mm_gemm + mm_rope_apply: same bits)."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    if (x2d.dtype != torch.bfloat16 or D != 128 or (N % 128) or (rope_cols % 128) or M < 256 or not _fused_rope()
+            or cos.dtype != torch.float32 or cos.shape[-1] != D // 2):
+        return None
+    out = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    call("mm_gemm_rope_fwd", dt(x2d), M, N, K, _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), int(rope_cols),
+         int(D), _p(cos), _p(sin), _stream())
+    return out
+
+
 def gemm_swiglu_bwd(dy2d, wd, gu, I):
     """dgu [M, 2I] from dy [M, H], down_proj weight [H, I] and the saved pre-activations; None -> two-launch form."""
     M, H = dy2d.shape

@@ -140,10 +140,11 @@ class DecoderLayer(nn.Module):
             return self.decode_step(x, cos, sin, key_mask, B, cache)
         a = self.self_attn
         h, x = self.input_layernorm(x)
-        qkv = Fm.linear(h, a._wqkv, a._bqkv, dummy=grad_dummy(a.q_proj.weight))
-        if cache is None:
-            o = Fm.rope_attention(qkv, cos, sin, key_mask, B, S, a.Hq, a.Hkv, a.D, True, a.D ** -0.5)
+        if cache is None:      # projection (+ RoPE in its epilogue) + attention as one autograd node
+            o = Fm.qkv_rope_attention(h, a._wqkv, a._bqkv, cos, sin, key_mask, B, S, a.Hq, a.Hkv, a.D, True, a.D ** -0.5,
+                                      dummy=grad_dummy(a.q_proj.weight))
         else:
+            qkv = Fm.linear(h, a._wqkv, a._bqkv, dummy=grad_dummy(a.q_proj.weight))
             o = cache.attend(qkv, cos, sin, key_mask, B, S, a)
         x = a.o_proj(o, residual=x)
         h, x = self.post_attention_layernorm(x)

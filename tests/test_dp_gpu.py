@@ -86,7 +86,7 @@ def test_dp2_equals_grad_accumulation(tmp_path):
     assert sharded[0][5] + sharded[1][5] <= repl[0][5] + 16 * sharded[0][4] and sharded[0][5] < 0.6 * repl[0][5]
     for k in repl[0][2]:
         a, b = torch.from_numpy(sharded[0][2][k]), torch.from_numpy(repl[0][2][k])
-        assert float((a - b).norm() / (b.norm() + 1e-12)) < 1e-5, k             # differ only by the summation order of the norm
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 1e-4, k             # summation order of the norm; the fp32 attention backward sums dK/dV with float atomics
     r0 = sharded[0]
     dp_params, early, nb = r0[2], r0[3], r0[4]
     assert nb > 1

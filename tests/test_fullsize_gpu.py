@@ -161,18 +161,16 @@ def test_config3_grad_accumulation_linearity_8b(big):
     torch.cuda.empty_cache()
 
 
-def test_config3_trainer_steps_8b_b4_s2048(big):
-    """The DP = 1 leg of config 2/3 at its real size through the trainer: B = 4, S = 2048, FULL mode, AdamW every step, batches
-    staged by the prefetcher (what bench.py times).  No oracle finishes at this size, so properties: the loss of a repeated batch
-    falls, the global gradient norm is finite and clipped updates move the weights, and -- since every kernel on the bf16 path
-    is deterministic (sorted embedding gradient, atomics-free attention backward) -- a second trainer started from the same
-    weights reproduces the loss sequence and the final weights BIT FOR BIT."""
+def _trainer_steps_property_test(m, V, B, S, n_img, P, img, seed, ids=None):
+    """Through the trainer at full size: FULL mode, AdamW every step, batches staged by the prefetcher (what bench.py times).  No
+    oracle finishes at this size, so properties: the loss of a repeated batch falls, the global gradient norm is finite and clipped
+    updates move the weights, and -- since every kernel on the bf16 path is deterministic (sorted embedding gradient, atomics-free
+    attention backward) -- a second trainer started from the same weights reproduces the loss sequence and the final weights BIT
+    FOR BIT."""
     import bench
     from multimeditron_amd.train.prefetch import DevicePrefetcher
     from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
-    m, llm = big
-    V = llm["vocab_size"] + 2
-    host, _ = bench.synthetic_batch(4, 2048, 1, 256, V, (V - 2, V - 1, 128002), 21, "cpu", 224, collator_form=True)
+    host, _ = bench.synthetic_batch(B, S, n_img, P, V, ids or (V - 2, V - 1, 128002), seed, "cpu", img, collator_form=True)
     flat = m.flat_params()
     w0 = flat.data.clone()
     runs = []
@@ -207,6 +205,19 @@ def test_config3_trainer_steps_8b_b4_s2048(big):
     torch.cuda.empty_cache()
 
 
+def test_config3_trainer_steps_8b_b4_s2048(big):
+    """The DP = 1 leg of config 2/3 at its real size: B = 4, S = 2048, one image per sample."""
+    m, llm = big
+    _trainer_steps_property_test(m, llm["vocab_size"] + 2, 4, 2048, 1, 256, 224, 21)
+
+
+def test_config4_trainer_steps_8b_b2_s4096_4img(big):
+    """BASELINE config 4 at its real size through the trainer: S = 4096, four interleaved images per sample (1032 modality tokens
+    with their delimiters), micro-batch 2: forward, backward (embed-splice with 8 spans, S = 4096 attention backward) and AdamW."""
+    m, llm = big
+    _trainer_steps_property_test(m, llm["vocab_size"] + 2, 2, 4096, 4, 256, 224, 22)
+
+
 def test_config5_qwen2_7b_shapes():
     """Alternate embedder + LLM plug (SigLIP-so400m/14@384: 729 tokens, no CLS, 16 heads x 72; Qwen2-7B: QKV bias,
     28/4 heads, vocab 152064) behind the same modality API, at full size."""
@@ -221,3 +232,5 @@ def test_config5_qwen2_7b_shapes():
     assert torch.equal(fwd(m, b).logits, o.logits)
     ids = m.generate(dict(b), max_new_tokens=3, temperature=0.1, do_sample=False)
     assert ids.shape[0] == 1 and 1 <= ids.shape[1] <= 3 and ids.dtype == torch.int64
+    # BASELINE config 5 through the trainer at its real size: B = 4, S = 2048, one 729-token SigLIP image per sample, FULL mode
+    _trainer_steps_property_test(m, V, 4, 2048, 1, 729, 384, 23, ids=(V - 2, V - 1, 151646))

@@ -696,6 +696,36 @@ def test_fused_swiglu_gemm_bit_identical_to_two_launch_form(K, M, I, Kd):
     assert dgu_f is not None and torch.equal(dgu_f, dgu)
 
 
+@pytest.mark.parametrize("M,Hq,Hkv,Kd,bias", [(512, 4, 1, 128, False), (300, 3, 2, 192, True), (1024, 8, 2, 320, False), (2048, 32, 8, 512, True)])
+def test_fused_rope_gemm_bit_identical_to_two_launch_form(K, M, Hq, Hkv, Kd, bias):
+    """mm_gemm_rope_fwd (RoPE as the epilogue of the fused q|k|v projection) against mm_gemm + mm_rope_apply: same products in the
+    same K order, the projection rounded to bf16 before the rotation, the rotation's arithmetic shared (rope_lo / rope_hi): the
+    outputs must be BIT-identical (ragged row counts, an odd head count = a half-empty last tile, Qwen2's bias); and against fp32 torch."""
+    dtype, D = torch.bfloat16, 128
+    N = (Hq + 2 * Hkv) * D
+    x = rnd((M, Kd), dtype, 211).cuda()
+    w = rnd((N, Kd), dtype, 212, 0.05).cuda()
+    b = rnd((N,), dtype, 213, 0.5).cuda() if bias else None
+    pos = torch.arange(M, device="cuda", dtype=torch.int64) % 777
+    inv = (1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))).cuda()
+    cos, sin = K.rope_table(pos, inv, True)
+    fused = K.gemm_rope_fwd(x, w, b, (Hq + Hkv) * D, D, cos, sin)
+    assert fused is not None
+    two = K.linear_fwd(x, w, bias=b)
+    plain = two.clone()
+    K.rope_apply_(two, M, Hq + Hkv, D, N, cos, sin)
+    assert torch.equal(fused, two)
+    assert torch.equal(fused[:, (Hq + Hkv) * D:], plain[:, (Hq + Hkv) * D:]) and not torch.equal(fused[:, :D], plain[:, :D])
+    ref = x.float() @ w.float().t() + (b.float() if bias else 0.0)
+    r = ref[:, : (Hq + Hkv) * D].view(M, Hq + Hkv, D)
+    c, s_ = cos.view(M, 1, D // 2), sin.view(M, 1, D // 2)
+    rot = torch.cat([r[..., : D // 2] * c - r[..., D // 2:] * s_, r[..., D // 2:] * c + r[..., : D // 2] * s_], dim=-1)
+    assert rel(fused[:, : (Hq + Hkv) * D].float(), rot.reshape(M, -1)) < 2e-2
+    # the adjoint used by backward still inverts the fused forward
+    K.rope_apply_(two, M, Hq + Hkv, D, N, cos, sin, inverse=True)
+    assert rel(two.float(), plain.float()) < 1e-2
+
+
 def test_embedding_out_of_range_id_raises(K):      # noqa: F811
     """nn.Embedding raises for an id outside the table (the reference embeds every id of the batch, model.py:433).  Here the
     lookup never reads out of bounds and the error surfaces without a stall: at the next lookup after the check has completed,

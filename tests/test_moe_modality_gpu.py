@@ -151,7 +151,7 @@ def test_shipped_cross_attn_recipes_construct_and_train(tmp_path, pep):
     assert AutoModality._cls("moe_meditron_clip_shared") is AutoModality._cls("moe_meditron_clip")      # the recipes' spelling
 
     def gate(px):
-        logits = px.float().mean(dim=(2, 3)) @ torch.ones(5, 3, device=px.device) * torch.arange(5, device=px.device).float()
+        logits = px.float().mean(dim=(2, 3)) @ torch.ones(3, 5, device=px.device) * torch.arange(5, device=px.device).float()
         return logits, logits.topk(1, dim=-1).indices, torch.softmax(logits, dim=-1)
 
     torch.manual_seed(0)
