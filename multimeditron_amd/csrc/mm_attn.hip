@@ -2249,6 +2249,42 @@ struct DecodeArgs {
   int* sync;            // [B*Hkv] arrival counters, zero on entry and left zero (NULL: merge in a second launch)
 };
 
+// element d of the merged output row from its nsplit partial records [m, l, o[D]] (in slice order: the result does not depend on
+// who merges).  The records' loads are issued EIGHT slices at a time before anything is combined: written as one load per loop
+// trip the merge was a chain of ~3 * nsplit dependent memory round trips (12.7 us for a few KB; 50 us inside the last-arriving
+// workgroup of the single-launch form, whose records come from beyond L2).
+template <int D>
+__device__ __forceinline__ bf16 decode_merge_one(const float* rec, int nsplit, int d) {
+  float mn = -INFINITY;
+  for (int s0 = 0; s0 < nsplit; s0 += 8) {
+    float mv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mv[u] = __builtin_nontemporal_load(rec + (int64_t)min(s0 + u, nsplit - 1) * (D + 2));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mn = fmaxf(mn, mv[u]);
+  }
+  float lt = 0.f, ot = 0.f;
+  for (int s0 = 0; s0 < nsplit; s0 += 8) {
+    float mv[8], lv[8], ov[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* r = rec + (int64_t)min(s0 + u, nsplit - 1) * (D + 2);
+      mv[u] = __builtin_nontemporal_load(r);
+      lv[u] = __builtin_nontemporal_load(r + 1);
+      ov[u] = __builtin_nontemporal_load(r + 2 + d);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u < nsplit) {
+        const float al = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mv[u] - mn);
+        lt += lv[u] * al;
+        ot += ov[u] * al;
+      }
+    }
+  }
+  return (bf16)(lt > 0.f ? ot / lt : 0.f);               // no visible key: 0, as in the prefill kernels
+}
+
 template <int D, int G>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(DecodeArgs a) {
   constexpr int LPK = D / 8;            // lanes per key row
@@ -2340,52 +2376,49 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(DecodeArgs a) 
       ot += red[ww][g][d] * al;
     }
     float* rec = a.ws + (((int64_t)b * a.Hq + hkv * G + g) * a.nsplit + split) * (D + 2);
-    rec[2 + d] = ot;
-    if (d == 0) { rec[0] = mn; rec[1] = lt; }
+    if (a.sync) {          // read by another workgroup of this launch: write-through (sc1) stores, see the hand-off below
+      __hip_atomic_store(rec + 2 + d, ot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == 0) {
+        __hip_atomic_store(rec, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + 1, lt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      rec[2 + d] = ot;
+      if (d == 0) { rec[0] = mn; rec[1] = lt; }
+    }
   }
   if (a.sync == nullptr) return;
   // the slice that arrives LAST merges all slices of this (batch, kv head) -- in slice order, so the result does not
   // depend on which one that is -- and leaves the counter at zero for the next step
+  // Hand-off per cdna_hip_programming.md Guideline 16 (counter form): the records are stored write-through (sc1), every storing
+  // wave drains its stores, ONE lane takes a ticket; the last arriver makes ONE agent-scope acquire (invalidates this CU's L1)
+  // before the workgroup reads the other slices' records.  (Round 2 had every thread run __threadfence() twice; an agent-scope
+  // release per workgroup -- buffer_wbl2 with an L2 full of dirty lines -- still cost 4x the merge launch it replaced.)
   __shared__ int last;
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int old = atomicAdd(a.sync + b * a.Hkv + hkv, 1);
+  if (threadIdx.x == 0) {      // no agent-scope release: the records went out write-through (sc1) and every wave has drained its stores
+    const int old = __hip_atomic_fetch_add(a.sync + b * a.Hkv + hkv, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = old == a.nsplit - 1;
-    if (last) a.sync[b * a.Hkv + hkv] = 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.sync + b * a.Hkv + hkv, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();
   for (int i = threadIdx.x; i < G * D; i += 256) {
     const int g = i / D, d = i % D;
     const int64_t row = (int64_t)b * a.Hq + hkv * G + g;
-    const float* rec = a.ws + row * a.nsplit * (D + 2);
-    float mn = -INFINITY;
-    for (int sp = 0; sp < a.nsplit; ++sp) mn = fmaxf(mn, __builtin_nontemporal_load(rec + sp * (D + 2)));
-    float lt = 0.f, ot = 0.f;
-    for (int sp = 0; sp < a.nsplit; ++sp) {
-      const float al = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(__builtin_nontemporal_load(rec + sp * (D + 2)) - mn);
-      lt += __builtin_nontemporal_load(rec + sp * (D + 2) + 1) * al;
-      ot += __builtin_nontemporal_load(rec + sp * (D + 2) + 2 + d) * al;
-    }
-    ((bf16*)a.out)[row * D + d] = (bf16)(lt > 0.f ? ot / lt : 0.f);
+    ((bf16*)a.out)[row * D + d] = decode_merge_one<D>(a.ws + row * a.nsplit * (D + 2), a.nsplit, d);
   }
 }
 
 template <int D>
 __global__ void attn_decode_merge_kernel(const float* ws, int nsplit, bf16* out) {
   const int row = blockIdx.x, d = threadIdx.x;          // row = b * Hq + hq
-  const float* rec = ws + (int64_t)row * nsplit * (D + 2);
-  float mn = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) mn = fmaxf(mn, rec[s * (D + 2)]);
-  float lt = 0.f, ot = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float al = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(rec[s * (D + 2)] - mn);
-    lt += rec[s * (D + 2) + 1] * al;
-    ot += rec[s * (D + 2) + 2 + d] * al;
-  }
-  out[(int64_t)row * D + d] = (bf16)(lt > 0.f ? ot / lt : 0.f);     // no visible key: 0, as in the prefill kernels
+  out[(int64_t)row * D + d] = decode_merge_one<D>(ws + (int64_t)row * nsplit * (D + 2), nsplit, d);
 }
 
 int g_attn_fwd_waves = 8;     // waves per workgroup of the D=128 forward (mm_set_option "attn_fwd_waves": 8 or 4)

@@ -609,7 +609,7 @@ __device__ __forceinline__ void gemm_epilogue_rope(const GemmArgs& g, f32x4 (&ac
   mw = __builtin_amdgcn_readfirstlane(mw);
   const int hb = __builtin_amdgcn_readfirstlane(n0 + (wn >> 1) * 128);          // first column of the wave's head
   const int dlo = __builtin_amdgcn_readfirstlane((wn & 1) * 32);
-  const bool rot = n0 < g.rope_cols;
+  const bool rot = hb < g.rope_cols;                                             // per HEAD: a tile may hold the last k head and the first v head
   const int rows = g.M - mw;
   auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)rows * g.ldc * 2);
   auto rcs = make_rsrc(g.rope_cos + (int64_t)mw * 64, rot ? (int64_t)rows * 64 * 4 : 0);
@@ -1128,6 +1128,226 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Decode-step fusions on the weight-streaming kernel (round 3).  A decode step of the 8B decoder was ~320 launches of which
+// ~190 were tiny (RMSNorm of 4 rows, SwiGLU, RoPE + cache append, the split merge): 4.5-6 us each on the timeline for a few
+// KB of work.  Three of them become epilogues of the GEMM that produces their input (same arithmetic, same rounding points):
+//   MODE 1  gate|up + SwiGLU     a workgroup streams 8 gate rows and the 8 matching up rows of the fused [2I, K] weight; after the
+//                                K-split sums meet in LDS a lane has g and u of a feature: act = bf16(bf16(silu(g)) * u)
+//   MODE 2  q|k|v + RoPE + KV-cache append   8 rows d .. d+7 and their rotate_half partners d+64 .. of one 128-wide head; the
+//                                epilogue rotates q / k heads (rope_lo / rope_hi), writes q|k|v and appends k, v to the cache row
+//   norm tail (MODE 0)           C = x W^T + residual, then y = RMSNorm(C) * w for the NEXT projection, computed by the workgroup
+//                                that finishes last (arrival counter; write-through stores + one agent-scope acquire by the last
+//                                arriver: cdna_hip_programming.md Guideline 16) with rmsnorm_fwd_kernel's own row routine (same bits)
+// ------------------------------------------------------------------------------------------------------
+struct SkinnyArgs {
+  int M, N, K;
+  const bf16* A; int lda;
+  const bf16* B; int ldb;
+  bf16* C; int ldc;
+  const bf16* bias;
+  const bf16* residual; int ldr;
+  int I;                                        // MODE 1: intermediate size (B = [2I, K], C = act [M, I])
+  int Hq, Hkv;                                  // MODE 2
+  const float* cos_t; const float* sin_t;       // [M, 64]
+  bf16* kdst; bf16* vdst; int64_t dstride;      // cache row of this step for sequence 0; elements between sequences
+  const bf16* norm_w; float eps; bf16* Y; int ldy; unsigned* counter;      // norm tail (norm_w == nullptr: none)
+};
+
+// RMSNorm of R rows by 256 threads: EXACTLY rmsnorm_fwd_kernel's arithmetic and summation order (mm_rowwise.hip), so the fused
+// tail gives the bits of the separate launch.  x is read with sc1 loads (written by other workgroups of this launch); the loads
+// of all R rows are issued before the first reduction (one memory round trip for the tail, not one per row).
+template <int CH, int R>
+__device__ __forceinline__ void rmsnorm_rows_256(const bf16* x, int ldx, const bf16* w, int H, float eps, bf16* y, int ldy, int nrows, float* red) {
+  const int t = threadIdx.x;
+  bf16x8 xv[R][CH];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    auto rx = make_rsrc(x + (int64_t)r * ldx, r < nrows ? (int64_t)H * 2 : 0);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int e = (c * 256 + t) * 8;
+      xv[r][c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, (t < 256 && e < H) ? (unsigned)e * 2u : 0xFFFFFFFFu, 0, 16));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r < nrows) {                                     // uniform
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int e = (c * 256 + t) * 8;
+        if (t < 256 && e < H) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float f = (float)xv[r][c][i]; ss += f * f; }
+        }
+      }
+      ss = block_sum_256(ss, red);
+      const float rs = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int e = (c * 256 + t) * 8;
+        if (t < 256 && e < H) {
+          const bf16x8 wv = *(const bf16x8*)(w + e);
+          bf16x8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float nrm = (float)(bf16)((float)xv[r][c][i] * rs);
+            o[i] = (bf16)((float)wv[i] * nrm);
+          }
+          *(bf16x8*)(y + (int64_t)r * ldy + e) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_skinny_fused_kernel(SkinnyArgs g) {
+  __shared__ float red[8][4][64];
+  __shared__ float nred[8];
+  __shared__ int s_last;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = l & 15, kc = l >> 4;
+  int wr;                                                   // the lane's row of W (as MFMA A-operand row `row`), -1 = none
+  if constexpr (MODE == 1) {
+    const int f = blockIdx.x * 8 + (row & 7);
+    wr = f < g.I ? f + (row >> 3) * g.I : -1;
+  } else if constexpr (MODE == 2) {
+    wr = (blockIdx.x >> 3) * 128 + (blockIdx.x & 7) * 8 + (row & 7) + (row >> 3) * 64;
+  } else {
+    wr = blockIdx.x * 16 + row;
+    if (wr >= g.N) wr = -1;
+  }
+  auto rw = make_rsrc(g.B, (int64_t)(MODE == 1 ? 2 * g.I : g.N) * g.ldb * 2);
+  auto rx = make_rsrc(g.A, (int64_t)g.M * g.lda * 2);
+  const int nks = (g.K + 31) / 32;
+  const int per = (nks + 7) / 8;
+  const int ks0 = w * per, ks1 = min(nks, ks0 + per);
+  const unsigned wrow = wr < 0 ? 0xFFFFFFFFu : (unsigned)wr * (unsigned)g.ldb * 2u, xrow = (unsigned)(row * g.lda) * 2u;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;
+  for (int ks = ks0; ks < ks1; ks += U) {
+    u32x4 fw[U], fx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (ks + u) * 32 + kc * 8;
+      const bool ok = (ks + u) < ks1 && k < g.K;
+      fw[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, (ok && wr >= 0) ? wrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, 0);
+      fx[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[u]), __builtin_bit_cast(bf16x8, fx[u]), acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][r][l] = acc[r];
+  __syncthreads();
+  // wave 0, lane: m = l & 15, local W rows 4 * (l >> 4) + r
+  const int m = l & 15, gq = l >> 4;
+  if (w == 0 && m < g.M) {
+    if constexpr (MODE == 0) {
+      const int n = blockIdx.x * 16 + 4 * gq;
+      if (n < g.N) {                                         // N % 4 == 0 (host)
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < 8; ++ww) t += red[ww][r][l];
+          if (g.bias) t += (float)g.bias[n + r];
+          if (g.residual) t += (float)g.residual[(int64_t)m * g.ldr + n + r];
+          o[r] = (bf16)t;
+        }
+        auto rc = make_rsrc(g.C + (int64_t)m * g.ldc, (int64_t)g.N * 2);
+        // sc1 (write-through) when another workgroup will read C inside this launch (the norm tail)
+        if (g.norm_w) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rc, (unsigned)n * 2u, 0, 16);
+        else *(bf16x4*)(g.C + (int64_t)m * g.ldc + n) = o;
+      }
+    } else if (gq < 2) {                                     // MODE 1 / 2: lanes 0-31 own the pairs (own rows, lane + 32's rows)
+      float v1[4], v2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) { a += red[ww][r][l]; b += red[ww][r][l + 32]; }
+        v1[r] = a;
+        v2[r] = b;
+      }
+      if constexpr (MODE == 1) {
+        const int f = blockIdx.x * 8 + 4 * gq;
+        if (f < g.I) {                                       // I % 4 == 0 (host)
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gf = (float)(bf16)v1[r], uf = (float)(bf16)v2[r];
+            const float sg = (float)(bf16)(gf / (1.0f + __expf(-gf)));
+            o[r] = (bf16)(sg * uf);
+          }
+          *(bf16x4*)(g.C + (int64_t)m * g.ldc + f) = o;
+        }
+      } else {
+        const int h = blockIdx.x >> 3, d = (blockIdx.x & 7) * 8 + 4 * gq;
+        bf16x4 o1, o2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = v1[r], b = v2[r];
+          if (g.bias) { a += (float)g.bias[h * 128 + d + r]; b += (float)g.bias[h * 128 + d + 64 + r]; }
+          o1[r] = (bf16)a;
+          o2[r] = (bf16)b;
+        }
+        if (h < g.Hq + g.Hkv) {
+          const f32x4 c4 = *(const f32x4*)(g.cos_t + (int64_t)m * 64 + d), s4 = *(const f32x4*)(g.sin_t + (int64_t)m * 64 + d);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = (float)o1[r], b = (float)o2[r];
+            o1[r] = (bf16)rope_lo(a, b, c4[r], s4[r]);
+            o2[r] = (bf16)rope_hi(a, b, c4[r], s4[r]);
+          }
+        }
+        bf16* cp = g.C + (int64_t)m * g.ldc + h * 128 + d;
+        *(bf16x4*)cp = o1;
+        *(bf16x4*)(cp + 64) = o2;
+        if (h >= g.Hq) {
+          bf16* dp = (h < g.Hq + g.Hkv ? g.kdst + (h - g.Hq) * 128 : g.vdst + (h - g.Hq - g.Hkv) * 128) + (int64_t)m * g.dstride + d;
+          *(bf16x4*)dp = o1;
+          *(bf16x4*)(dp + 64) = o2;
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 0) {
+    if (!g.norm_w) return;
+    // ---- norm tail: the workgroup that arrives last normalises the M rows of C
+    // Hand-off (cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md "Valid forms"): every byte of C is stored sc1
+    // (write-through) by wave 0, which drains its stores before its lane 0 takes the ticket -- no agent-scope RELEASE (a
+    // `buffer_wbl2` per workgroup cost ~10 us per launch here: the L2 is full of dirty KV-cache and activation lines); the last
+    // arriver makes ONE agent-scope ACQUIRE and reads C with sc1 loads.
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this workgroup's C stores (wave 0's, sc1) have left
+      const unsigned old = __hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (old + 1u) == gridDim.x;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(g.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch (same stream: ordered)
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int r = 0; r < g.M; r += 4) {                   // four rows' loads in flight at a time
+      const bf16* xr = g.C + (int64_t)r * g.ldc;
+      bf16* yr = g.Y + (int64_t)r * g.ldy;
+      const int nr = min(4, g.M - r);
+      if (g.N <= 2048) rmsnorm_rows_256<1, 4>(xr, g.ldc, g.norm_w, g.N, g.eps, yr, g.ldy, nr, nred);
+      else if (g.N <= 4096) rmsnorm_rows_256<2, 4>(xr, g.ldc, g.norm_w, g.N, g.eps, yr, g.ldy, nr, nred);
+      else rmsnorm_rows_256<4, 4>(xr, g.ldc, g.norm_w, g.N, g.eps, yr, g.ldy, nr, nred);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // exact-fp32 GEMM (parity path).  64x64 tile, BK = 16, 4 waves each 32x32 (2x2 of 16x16x4 f32 MFMA).
 // LDS images are [k][x] for both operands (any global layout is re-tiled by scalar loads).
@@ -1414,6 +1634,65 @@ extern "C" int mm_gemm_sumsq(int dtype, int layout, int M, int N, int K, const v
   const int rc = gemm_launch(g, dtype, layout, (hipStream_t)stream);
   if (rc != MM_OK) return rc;
   hipLaunchKernelGGL(sumsq2d_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16*)C, M, N, ldc, partials);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+
+// ---- decode-step entry points (KV-cache decode of generate, reference model.py:595-602: M = batch <= 16 rows) ------------------
+static int skinny_common(int dtype, int M, int K, const void* X, int ldx, const void* W, int ldw, int64_t wrows) {
+  if (dtype != MM_BF16) return MM_ERR_UNSUPPORTED;
+  if (M <= 0 || M > 16 || K <= 0 || !X || !W) return MM_ERR_ARG;
+  if ((ldx & 7) || (ldw & 7) || !mm_aligned16(X) || !mm_aligned16(W)) return MM_ERR_ALIGN;
+  if (wrows * ldw * 2 >= 0xFFFFFFFFll || (int64_t)16 * ldx * 2 >= 0xFFFFFFFFll) return MM_ERR_UNSUPPORTED;
+  return MM_OK;
+}
+
+extern "C" int mm_decode_gateup_swiglu(int dtype, int M, int I, int K, const void* X, int ldx, const void* Wgu, int ldw, void* ACT, int ldact,
+                                       void* stream) {
+  int rc = skinny_common(dtype, M, K, X, ldx, Wgu, ldw, (int64_t)2 * I);
+  if (rc != MM_OK) return rc;
+  if (I <= 0 || !ACT) return MM_ERR_ARG;
+  if ((I & 3) || (ldact & 3) || (((uintptr_t)ACT) & 7)) return MM_ERR_ALIGN;
+  SkinnyArgs g{};
+  g.M = M; g.N = 2 * I; g.K = K; g.A = (const bf16*)X; g.lda = ldx; g.B = (const bf16*)Wgu; g.ldb = ldw; g.C = (bf16*)ACT; g.ldc = ldact; g.I = I;
+  hipLaunchKernelGGL(gemm_skinny_fused_kernel<1>, dim3((unsigned)((I + 7) / 8)), dim3(512), 0, (hipStream_t)stream, g);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_decode_qkv_rope_append(int dtype, int M, int Hq, int Hkv, int D, int K, const void* X, int ldx, const void* W, int ldw,
+                                         const void* bias, void* QKV, int ldqkv, const float* cos_t, const float* sin_t, void* kdst, void* vdst,
+                                         int64_t dstride, void* stream) {
+  if (Hq <= 0 || Hkv <= 0) return MM_ERR_ARG;
+  const int N = (Hq + 2 * Hkv) * D;
+  int rc = skinny_common(dtype, M, K, X, ldx, W, ldw, N);
+  if (rc != MM_OK) return rc;
+  if (D != 128) return MM_ERR_UNSUPPORTED;
+  if (!QKV || !cos_t || !sin_t || !kdst || !vdst) return MM_ERR_ARG;
+  if ((ldqkv & 3) || (dstride & 3) || (((uintptr_t)QKV) & 7) || (((uintptr_t)kdst) & 7) || (((uintptr_t)vdst) & 7) || (((uintptr_t)cos_t) & 15) ||
+      (((uintptr_t)sin_t) & 15))
+    return MM_ERR_ALIGN;
+  SkinnyArgs g{};
+  g.M = M; g.N = N; g.K = K; g.A = (const bf16*)X; g.lda = ldx; g.B = (const bf16*)W; g.ldb = ldw; g.C = (bf16*)QKV; g.ldc = ldqkv;
+  g.bias = (const bf16*)bias; g.Hq = Hq; g.Hkv = Hkv; g.cos_t = cos_t; g.sin_t = sin_t; g.kdst = (bf16*)kdst; g.vdst = (bf16*)vdst; g.dstride = dstride;
+  hipLaunchKernelGGL(gemm_skinny_fused_kernel<2>, dim3((unsigned)(N / 16)), dim3(512), 0, (hipStream_t)stream, g);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_decode_linear_norm(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* residual, int ldr,
+                                     void* C, int ldc, const void* norm_w, float eps, void* Y, int ldy, void* counter, void* stream) {
+  int rc = skinny_common(dtype, M, K, X, ldx, W, ldw, N);
+  if (rc != MM_OK) return rc;
+  if (N <= 0 || !C || !norm_w || !Y || !counter) return MM_ERR_ARG;
+  if ((N & 7) || N > 8192) return MM_ERR_UNSUPPORTED;
+  if ((ldc & 7) || (ldy & 7) || (residual && (ldr & 3)) || !mm_aligned16(C) || !mm_aligned16(Y) || !mm_aligned16(norm_w) || (((uintptr_t)counter) & 3))
+    return MM_ERR_ALIGN;
+  SkinnyArgs g{};
+  g.M = M; g.N = N; g.K = K; g.A = (const bf16*)X; g.lda = ldx; g.B = (const bf16*)W; g.ldb = ldw; g.C = (bf16*)C; g.ldc = ldc;
+  g.residual = (const bf16*)residual; g.ldr = ldr; g.norm_w = (const bf16*)norm_w; g.eps = eps; g.Y = (bf16*)Y; g.ldy = ldy; g.counter = (unsigned*)counter;
+  hipLaunchKernelGGL(gemm_skinny_fused_kernel<0>, dim3((unsigned)((N + 15) / 16)), dim3(512), 0, (hipStream_t)stream, g);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

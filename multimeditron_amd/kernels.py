@@ -154,6 +154,46 @@ def gemm_rope_fwd(x2d, w, bias, rope_cols, D, cos, sin):
     return out
 
 
+# ---- decode-step fusions (M = batch <= 16 rows; see include/mm_hip.h) ----------------------------------------------------------
+def decode_gateup_swiglu(x2d, wgu, I):
+    M, K = x2d.shape
+    act = torch.empty((M, I), dtype=x2d.dtype, device=x2d.device)
+    call("mm_decode_gateup_swiglu", dt(x2d), M, I, K, _p(x2d), x2d.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), _stream())
+    return act
+
+
+def decode_qkv_rope_append(x2d, w, bias, Hq, Hkv, D, cos, sin, kcache, vcache, pos):
+    """qkv [B, (Hq+2Hkv)*D] = x @ w^T (+ bias) with RoPE on q / k and the append of roped k / v to cache[:, pos]."""
+    M, K = x2d.shape
+    assert kcache.stride(3) == 1 and kcache.stride(2) == D and vcache.stride(2) == D and kcache.stride(0) == vcache.stride(0)
+    qkv = torch.empty((M, (Hq + 2 * Hkv) * D), dtype=x2d.dtype, device=x2d.device)
+    call("mm_decode_qkv_rope_append", dt(x2d), M, Hq, Hkv, D, K, _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(qkv), qkv.stride(0),
+         _p(cos), _p(sin), _p(kcache[:, pos]), _p(vcache[:, pos]), kcache.stride(0), _stream())
+    return qkv
+
+
+_decode_counters = {}
+
+
+def decode_linear_norm(x2d, w, residual, norm_w, eps):
+    """-> (c, y): c = x @ w^T + residual, y = rmsnorm(c) * norm_w (the next projection's input), one launch."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    dev = x2d.device
+    cnt = _decode_counters.get(dev)
+    if cnt is None:
+        cnt = _decode_counters[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    c = torch.empty((M, N), dtype=x2d.dtype, device=dev)
+    y = torch.empty((M, N), dtype=x2d.dtype, device=dev)
+    call("mm_decode_linear_norm", dt(x2d), M, N, K, _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(residual),
+         residual.stride(0) if residual is not None else 0, _p(c), N, _p(norm_w), float(eps), _p(y), N, _p(cnt), _stream())
+    return c, y
+
+
+def decode_fusions():      # A/B switch (tools/decode_bench.py): MM_DECODE_FUSED=0 -> the separate launches
+    return _os.environ.get("MM_DECODE_FUSED", "1") != "0"
+
+
 def gemm_swiglu_bwd(dy2d, wd, gu, I):
     """dgu [M, 2I] from dy [M, H], down_proj weight [H, I] and the saved pre-activations; None -> two-launch form."""
     M, H = dy2d.shape
@@ -410,6 +450,9 @@ def attn_decode_supported(q_dtype, Hq, Hkv, D):
     return q_dtype == torch.bfloat16 and D in (64, 128) and Hq % Hkv == 0 and (Hq // Hkv) in (1, 2, 4, 7, 8)
 
 
+_decode_sync = {}
+
+
 def attn_decode(q, k, v, key_mask, scale):
     """One query token per sequence over a KV cache: q [B,Hq,D] (strided view ok), k/v [B,Skv,Hkv,D] -> out [B,Hq,D]."""
     B, Hq, D = q.shape
@@ -418,10 +461,17 @@ def attn_decode(q, k, v, key_mask, scale):
     ns = _lib.lib().mm_attn_decode_splits(B, Hkv, Skv)
     ws = torch.empty(B * Hq * ns * (D + 2), dtype=torch.float32, device=q.device)
     out = torch.empty((B, Hq, D), dtype=q.dtype, device=q.device)
-    # sync=None: the slices are merged by a second (tiny) launch.  The single-launch form (last-arriving slice merges;
-    # `sync` counters) is correct but SLOWER on MI355X: its device-scope fences write back / invalidate the XCD's whole L2
-    # once per workgroup (8.2 vs 5.2 ms/token on the 8B decoder), so it is not used.
+    # sync=None: the slices are merged by a second (tiny) launch.  The single-launch form (sync = arrival counters [B * Hkv]; the
+    # slice that arrives last merges) is correct but SLOWER on MI355X in every protocol tried: __threadfence() per thread (round 2:
+    # 8.2 vs 5.2 ms/token), one agent-scope release per workgroup (round 3: the partial kernel went from 18 to 75 us -- buffer_wbl2
+    # with an L2 full of dirty lines), write-through record stores + one acquire by the last arriver (33 us against 18 + 8 for the
+    # two launches: the merging workgroup starts only when the last slice is done and reads records that come from beyond L2).
+    # MM_DECODE_MERGE=fused selects it.
     sync = None
+    if _os.environ.get("MM_DECODE_MERGE", "launch") == "fused":
+        sync = _decode_sync.get(q.device)
+        if sync is None or sync.numel() < B * Hkv:
+            sync = _decode_sync[q.device] = torch.zeros(max(64, B * Hkv), dtype=torch.int32, device=q.device)
     call("mm_attn_decode", dt(q), _p(q), _p(k), _p(v), B, Skv, Hq, Hkv, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
          k.stride(2), v.stride(0), v.stride(1), v.stride(2), _p(key_mask), float(scale), _p(out), _p(ws), ns, _p(sync), _stream())
     return out

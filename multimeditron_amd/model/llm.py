@@ -130,10 +130,31 @@ class DecoderLayer(nn.Module):
         act = K.swiglu_fwd(K.linear_fwd(h, m._wgu.tensor()), m.I)
         return K.linear_fwd(act, m.down_proj.weight, residual=x)
 
+    @torch.no_grad()
+    def decode_step_fused(self, x, h, cos, sin, key_mask, B, cache, next_norm):
+        """The same decode step with the tiny launches folded into the weight-streaming GEMMs (round 3; csrc/mm_gemm.hip
+        gemm_skinny_fused_kernel): q|k|v + RoPE + cache append, o_proj + residual + the post-attention RMSNorm, gate|up + SwiGLU,
+        down_proj + residual + the NEXT layer's input RMSNorm (`next_norm`: that layer's input_layernorm, or the model's final norm).
+        x = residual stream, h = this layer's already normalised input.  -> (x, h of the next layer).  Same bits as decode_step."""
+        a, m = self.self_attn, self.mlp
+        Hq, Hkv, D = a.Hq, a.Hkv, a.D
+        qkv = K.decode_qkv_rope_append(h, a._wqkv.tensor(), a._bqkv.tensor() if a._bqkv is not None else None, Hq, Hkv, D, cos, sin,
+                                       cache.k, cache.v, cache.len)
+        cache.len += 1
+        o = K.attn_decode(qkv[:, : Hq * D].view(B, Hq, D), cache.k[:, : cache.len], cache.v[:, : cache.len], key_mask, D ** -0.5)
+        x, h2 = K.decode_linear_norm(o.view(B, Hq * D), a.o_proj.weight, x, self.post_attention_layernorm.weight, self.post_attention_layernorm.eps)
+        act = K.decode_gateup_swiglu(h2, m._wgu.tensor(), m.I)
+        return K.decode_linear_norm(act, m.down_proj.weight, x, next_norm.weight, next_norm.eps)
+
     def can_decode_step(self, x, B, S, cache):
         a = self.self_attn
         return (cache is not None and S == 1 and B <= 16 and x.dtype == torch.bfloat16 and not torch.is_grad_enabled()
                 and K.attn_decode_supported(x.dtype, a.Hq, a.Hkv, a.D))
+
+    def can_decode_step_fused(self, x, B, S, cache):
+        a = self.self_attn
+        return (self.can_decode_step(x, B, S, cache) and a.D == 128 and K.decode_fusions() and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192
+                and self.mlp.I % 4 == 0)
 
     def forward(self, x, cos, sin, key_mask, B, S, cache=None):
         if self.can_decode_step(x, B, S, cache):
@@ -284,9 +305,18 @@ class CausalLM(nn.Module):
         x = inputs_embeds.reshape(B * S, H)
         if not x.is_contiguous():
             x = x.contiguous()
-        for i, layer in enumerate(self.model.layers):
-            x = layer(x, cos, sin, key_mask, B, S, cache=cache[i] if cache else None)
-        x, _ = self.model.norm(x)
+        layers = self.model.layers
+        if cache and len(layers) and all(layer.can_decode_step_fused(x, B, S, cache[i]) for i, layer in enumerate(layers)):
+            # decode step: every RMSNorm rides on the GEMM in front of it (DecoderLayer.decode_step_fused); only the first is a launch
+            h, _ = K.rmsnorm_fwd(x, layers[0].input_layernorm.weight, layers[0].input_layernorm.eps)
+            for i, layer in enumerate(layers):
+                nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else self.model.norm
+                x, h = layer.decode_step_fused(x, h, cos, sin, key_mask, B, cache[i], nxt)
+            x = h                                            # = final norm of the last residual stream
+        else:
+            for i, layer in enumerate(layers):
+                x = layer(x, cos, sin, key_mask, B, S, cache=cache[i] if cache else None)
+            x, _ = self.model.norm(x)
         V = self.config.vocab_size
         if logits_to_keep:
             x = x.view(B, S, H)[:, -logits_to_keep:, :].reshape(-1, H)
