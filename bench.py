@@ -451,7 +451,7 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "seq_len": S, "images_per_sample": n_img,
                       "training_mode": args.mode,
-                      "optimizer": "AdamW every step (fused, fp32 master+m+v" + (f"; state sharded over the {world} ranks: reduce-scatter, "
+                      "optimizer": "AdamW every step (fused, fp32 master" + (" held as bf16 parameter + 16-bit remainder" if trainer.split_master else "") + " + fp32 m, v" + (f"; state sharded over the {world} ranks: reduce-scatter, "
                                    "update, all-gather)" if trainer.shard_optim else ")"), "parallelism": f"dp{world}",
                       **({"padding": "right-padded, lengths U[S/2, S] (key-mask path); tokens counted as S per sample"} if args.padded else {}),
                       "final_loss": round(float(loss), 4),

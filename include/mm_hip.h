@@ -309,6 +309,15 @@ int mm_comm_reduce_scatter(void* comm, int dtype, void* buf, int64_t count, void
 int mm_comm_all_gather(void* comm, int dtype, void* buf, int64_t count, void* stream);
 int mm_comm_finalize(void* comm);
 
+/* AdamW with the fp32 master weight held as (bf16 parameter, int16 remainder): master_bits = (p_bits << 16) + lo, p = RNE(master).
+ * Same update as mm_adamw_step (MM_BF16), 26 B instead of 28 B of HBM traffic per parameter and no separate fp32 copy; one
+ * remainder value in 2^17 (+0x8000, a round-to-even tie) is stored as 0x7FFF, i.e. the master moves by one fp32 ulp there.
+ * mm_master_split / mm_master_join convert between that form and an fp32 master (optimiser checkpoints keep fp32).              */
+int mm_adamw_step_split(void* p_bf16, const void* g_bf16, void* lo_i16, float* m, float* v, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, const float* clip, void* stream);
+int mm_master_split(const float* master, int64_t n, void* p_bf16, void* lo_i16, void* stream);
+int mm_master_join(const void* p_bf16, const void* lo_i16, int64_t n, float* master, void* stream);
+
 /* ---- image preprocessing on the device (optional row) ---------------------------------------------------
  * Replaces the CPU image processor the reference runs in its collator (image_modality.py:77,88-93 -> HF CLIPImageProcessor:
  * PIL resize BICUBIC, center crop, rescale 1/255, normalize) for an already decoded uint8 RGB image [src_h, src_w, 3] in HBM.

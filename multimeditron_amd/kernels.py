@@ -642,6 +642,25 @@ def adamw_step(p, g, master, m, v, lr, beta1, beta2, eps, wd, step, clip=None):
          float(eps), float(wd), int(step), _p(clip), _stream())
 
 
+def adamw_step_split(p, g, lo, m, v, lr, beta1, beta2, eps, wd, step, clip=None):
+    """AdamW on (bf16 parameter, int16 remainder) = the fp32 master in two halves (mm_adamw_step_split): 26 B per parameter."""
+    assert p.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and lo.dtype == torch.int16
+    call("mm_adamw_step_split", _p(p), _p(g), _p(lo), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(wd),
+         int(step), _p(clip), _stream())
+
+
+def master_split(master, p, lo):
+    """fp32 master -> p = RNE(master) (bf16) and the int16 remainder lo."""
+    call("mm_master_split", _p(master), master.numel(), _p(p), _p(lo), _stream())
+
+
+def master_join(p, lo):
+    """(bf16 parameter, int16 remainder) -> the fp32 master they encode."""
+    out = torch.empty(p.numel(), dtype=torch.float32, device=p.device)
+    call("mm_master_join", _p(p), _p(lo), p.numel(), _p(out), _stream())
+    return out
+
+
 def cast(src, dtype):
     dst = torch.empty(src.shape, dtype=dtype, device=src.device)
     call("mm_cast", dt(src), _DT[dtype], _p(src), _p(dst), src.numel(), _stream())

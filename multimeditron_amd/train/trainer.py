@@ -316,17 +316,24 @@ class MultimodalTrainer:
         else:
             self.pieces = None
             n_state = sum(e - s for s, e, _ in self.ranges)
-        self.master = torch.empty(n_state, dtype=torch.float32, device=dev)
+        # bf16 models keep the fp32 master weight as (the bf16 parameter itself, an int16 remainder): `self.master` then holds the
+        # remainders (mm_adamw_step_split: 26 B instead of 28 B of traffic per parameter, no second copy of the weights).  fp32
+        # models (the parity path) and MM_ADAMW_SPLIT=0 keep a separate fp32 master.
+        self.split_master = flat.dtype == torch.bfloat16 and flat.data.is_cuda and os.environ.get("MM_ADAMW_SPLIT", "1") != "0"
+        self.master = (torch.zeros(n_state, dtype=torch.int16, device=dev) if self.split_master      # master == parameter: remainder 0
+                       else torch.empty(n_state, dtype=torch.float32, device=dev))
         self.m = torch.zeros(n_state, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n_state, dtype=torch.float32, device=dev)
         self.state_off = []
         if self.shard_optim:
-            for a, b, _, o, _, _ in self.pieces:
-                self.master[o:o + b - a].copy_(flat.data[a:b])
+            if not self.split_master:
+                for a, b, _, o, _, _ in self.pieces:
+                    self.master[o:o + b - a].copy_(flat.data[a:b])
         else:
             off = 0
             for s, e, _ in self.ranges:
-                self.master[off:off + e - s].copy_(flat.data[s:e])          # device copy of the bf16 weights (plumbing)
+                if not self.split_master:
+                    self.master[off:off + e - s].copy_(flat.data[s:e])          # device copy of the bf16 weights (plumbing)
                 self.state_off.append(off)
                 off += e - s
         if self.world > 1 and not os.environ.get("MM_GEMM_PERSIST"):
@@ -515,6 +522,30 @@ class MultimodalTrainer:
             if w is not None:
                 w.wait()
 
+    def _adamw(self, a, b, off, lr, decay, total):
+        """AdamW on flat[a:b] with the state slice starting at `off`."""
+        n = b - a
+        args = (self.m[off:off + n], self.v[off:off + n], lr, self.betas[0], self.betas[1], self.eps, self.wd if decay else 0.0, self.step_count)
+        if self.split_master:
+            K.adamw_step_split(self.flat.data[a:b], self.flat.grad[a:b], self.master[off:off + n], *args, clip=total)
+        else:
+            K.adamw_step(self.flat.data[a:b], self.flat.grad[a:b], self.master[off:off + n], *args, clip=total)
+
+    def _state_pieces(self):
+        """(start, end, state offset) of every slice the optimiser state covers, in state order."""
+        if self.shard_optim:
+            return [(a, b, off) for a, b, _, off, _, _ in self.pieces]
+        return [(s0, e0, off) for (s0, e0, _), off in zip(self.ranges, self.state_off)]
+
+    def master_fp32(self):
+        """The fp32 master weights of the state slices, packed (what optimizer checkpoints hold)."""
+        if not self.split_master:
+            return self.master
+        out = torch.empty(self.master.numel(), dtype=torch.float32, device=self.master.device)
+        for a, b, off in self._state_pieces():
+            out[off:off + b - a].copy_(K.master_join(self.flat.data[a:b], self.master[off:off + b - a]))
+        return out
+
     def _optimizer_step_sharded(self, lr):
         """clip + AdamW on this rank's pieces, then the all-gathers (see _setup_sharded_pipeline)."""
         ex, g = self.exchanger, self.flat.grad
@@ -537,9 +568,7 @@ class MultimodalTrainer:
         def run():
             for bi in self._bucket_order:
                 for a, b, decay, off, _, _ in by_bucket.get(bi, ()):
-                    n = b - a
-                    K.adamw_step(self.flat.data[a:b], g[a:b], self.master[off:off + n], self.m[off:off + n], self.v[off:off + n], lr,
-                                 self.betas[0], self.betas[1], self.eps, self.wd if decay else 0.0, self.step_count, clip=total)
+                    self._adamw(a, b, off, lr, decay, total)
                 self._gather_works[bi] = ex.all_gather_params(self.flat.data, ex.buckets[bi])
 
         if self._opt_stream is not None:
@@ -645,9 +674,7 @@ class MultimodalTrainer:
         self.last_grad_norm = total
 
         def upd(s, e, decay, off):
-            n = e - s
-            K.adamw_step(self.flat.data[s:e], g[s:e], self.master[off:off + n], self.m[off:off + n], self.v[off:off + n], lr,
-                         self.betas[0], self.betas[1], self.eps, self.wd if decay else 0.0, self.step_count, clip=total)
+            self._adamw(s, e, off, lr, decay, total)
 
         if not self._blocks:
             for (s, e, decay), off in zip(self.ranges, self.state_off):
@@ -732,7 +759,7 @@ class MultimodalTrainer:
             os.makedirs(path, exist_ok=True)
         if rank != 0 and not self.shard_optim:
             return                                # replicated optimiser state: rank 0's files are everyone's
-        save_file({"master": self.master.detach().cpu(), "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu()},
+        save_file({"master": self.master_fp32().detach().cpu(), "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu()},
                   os.path.join(path, self._state_file()), metadata={"format": "pt"})
         with open(os.path.join(path, "trainer_state.json" if rank == 0 else f"trainer_state.rank{rank:05d}.json"), "w") as f:
             json.dump({"global_step": self.step_count, "micro_step": self._micro, "learning_rate": self.lr, "min_lr": self.min_lr,
@@ -755,15 +782,16 @@ class MultimodalTrainer:
         if load_model:
             self.model.load_checkpoint_weights(path, strict=True)
         with safe_open(os.path.join(path, self._state_file()), framework="pt", device="cpu") as f:
-            self.master.copy_(f.get_tensor("master"))
+            master = f.get_tensor("master").to(self.flat.device)
             self.m.copy_(f.get_tensor("exp_avg"))
             self.v.copy_(f.get_tensor("exp_avg_sq"))
-        with torch.no_grad():
-            if self.shard_optim:                  # my pieces from my master; the others' pieces came with the model weights
-                for a, b, _, off, _, _ in self.pieces:
-                    self.flat.data[a:b].copy_(self.master[off:off + b - a])
-            for (s0, e0, _), off in zip(self.ranges, self.state_off):
-                self.flat.data[s0:e0].copy_(self.master[off:off + e0 - s0])       # bf16 parameters = round(master)
+        with torch.no_grad():      # the master weights are authoritative: bf16 parameters = round(master) (my pieces; the others' came with the model)
+            for a, b, off in self._state_pieces():
+                if self.split_master:
+                    K.master_split(master[off:off + b - a].contiguous(), self.flat.data[a:b], self.master[off:off + b - a])
+                else:
+                    self.master[off:off + b - a].copy_(master[off:off + b - a])
+                    self.flat.data[a:b].copy_(master[off:off + b - a])
         self.step_count = int(st["global_step"])
         self._micro = 0
         return st

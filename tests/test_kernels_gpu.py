@@ -721,6 +721,36 @@ def test_adamw_and_gradnorm(K, dtype):
     assert rel(pg.float(), ref_p.detach()) < (1e-5 if dtype == torch.float32 else 5e-3)
 
 
+def test_adamw_split_master_equals_fp32_master(K):
+    """mm_adamw_step_split keeps the fp32 master as (bf16 parameter, int16 remainder): over several clipped steps the bf16 parameters
+    must equal those of mm_adamw_step with a separate fp32 master BIT FOR BIT, the joined master must stay within one fp32 ulp of it
+    (the one unrepresentable remainder, +0x8000, is stored as 0x7FFF), and split(join(.)) must be the identity."""
+    n = 1_000_003
+    g0 = torch.Generator().manual_seed(5)
+    w = (torch.randn(n, generator=g0) * 0.05).to(torch.bfloat16)
+    p_a, p_b = w.clone().cuda(), w.clone().cuda()
+    master = w.float().cuda()
+    lo = torch.zeros(n, dtype=torch.int16, device="cuda")
+    m_a, v_a, m_b, v_b = (torch.zeros(n, device="cuda") for _ in range(4))
+    for step in (1, 2, 3, 4):
+        g = (torch.randn(n, generator=g0) * (0.01 * step)).to(torch.bfloat16).cuda()
+        total = K.gradnorm([g], 1.0)
+        K.adamw_step(p_a, g, master, m_a, v_a, 3e-3, 0.9, 0.95, 1e-8, 0.01, step, clip=total)
+        K.adamw_step_split(p_b, g, lo, m_b, v_b, 3e-3, 0.9, 0.95, 1e-8, 0.01, step, clip=total)
+        torch.cuda.synchronize()
+        assert torch.equal(p_a, p_b), step
+        joined = K.master_join(p_b, lo)
+        ulp = (joined.view(torch.int32).long() - master.view(torch.int32).long()).abs()
+        assert int(ulp.max()) <= step, (step, int(ulp.max()))                      # at most one ulp per step, and only at exact ties
+        assert float((ulp > 0).float().mean()) < 1e-3
+        assert torch.equal(m_a, m_b) or float((m_a - m_b).abs().max()) < 1e-9
+    p2, lo2 = torch.empty_like(p_b), torch.empty_like(lo)
+    K.master_split(K.master_join(p_b, lo), p2, lo2)
+    assert torch.equal(p2, p_b) and torch.equal(lo2, lo)
+    K.master_split(master, p2, lo2)
+    assert torch.equal(p2, p_a)                                                     # p = round-to-nearest-even(master)
+
+
 @pytest.mark.parametrize("M,I,Kd", [(512, 256, 128), (300, 128, 64), (1024, 384, 320), (2048, 14336 // 8, 512)])
 def test_fused_swiglu_gemm_bit_identical_to_two_launch_form(K, M, I, Kd):
     """mm_gemm_swiglu_fwd / _bwd (SwiGLU as the epilogue of the gate|up GEMM and of down_proj's dgrad) against the separate
