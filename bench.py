@@ -140,12 +140,24 @@ def measure_gemm_roofline(trainer, batch):
             rec.append((e0, e1, 2.0 * M * w.shape[0] * Kd, ("NT+act", M, w.shape[0], Kd)))
         return out
 
-    K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd, K.linear_act_fwd = timed, timed_sf, timed_sb, timed_act
+    orig_rope = K.gemm_rope_fwd
+
+    def timed_rope(x2d, w, bias, rope_cols, D, cos, sin):      # the q|k|v projection with RoPE in its epilogue: mm_gemm_rope_fwd
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_rope(x2d, w, bias, rope_cols, D, cos, sin)
+        e1.record()
+        if out is not None:
+            M, Kd = x2d.shape
+            rec.append((e0, e1, 2.0 * M * w.shape[0] * Kd, ("NT+rope", M, w.shape[0], Kd)))
+        return out
+
+    K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd, K.linear_act_fwd, K.gemm_rope_fwd = timed, timed_sf, timed_sb, timed_act, timed_rope
     try:
         trainer.training_step(batch)
         torch.cuda.synchronize()
     finally:
-        K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd, K.linear_act_fwd = orig, orig_sf, orig_sb, orig_act
+        K.gemm, K.gemm_swiglu_fwd, K.gemm_swiglu_bwd, K.linear_act_fwd, K.gemm_rope_fwd = orig, orig_sf, orig_sb, orig_act, orig_rope
     tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in rec)
     tot_fl = sum(f for _, _, f, _ in rec)
     alg_bytes = sum(2.0 * (M * Kd + N * Kd + M * N) for _, _, _, (_, M, N, Kd) in rec)      # A, B, C once, bf16

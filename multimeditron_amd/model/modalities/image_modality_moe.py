@@ -117,8 +117,11 @@ class CrossAttention(nn.Module):
             o = Fm.cross_attention(q, kv, n, Nq, Nkv, h, d, self.scale, drop)
         else:
             # more than 512 keys: the flash kernels, narrower heads zero-padded to 64 / 128 as the SigLIP tower's are
-            if drop > 0.0:
-                raise NotImplementedError(f"attention dropout over {Nkv} keys is not built (mm_xattn_* holds <= 512 keys per query)")
+            if drop > 0.0 and not getattr(CrossAttention, "_warned_no_attn_drop", False):
+                import warnings
+                CrossAttention._warned_no_attn_drop = True      # outside the reference's recipes (P = 49, E = 5: 196 keys); say so, once
+                warnings.warn(f"CrossAttention over {Nkv} keys runs on the flash kernels, which have no attention-probability dropout "
+                              f"(mm_xattn_* holds <= 512 keys per query): attn_drop = {drop} is NOT applied; proj_drop still is.")
             hw = Fm.attention_head_width(d, x.dtype)
             if hw != d:
                 q, kv = Fm.head_pad(q, h, d, hw), Fm.head_pad(kv, 2 * h, d, hw)
@@ -130,22 +133,29 @@ class CrossAttention(nn.Module):
 
 
 def _run_experts(experts, pixels, post=None):
-    """Every expert tower on the same pixels, each on ITS OWN HIP stream: at the modality's size (ViT on a few hundred rows) the
-    towers are launch-latency-bound chains of short kernels, so E of them side by side take little more than one (the "batched
-    multi-expert ViT" of SURVEY 8f-4, done with streams instead of a grouped launch: same kernels, same results bit for bit).
-    Autograd replays each tower's backward on the stream its forward ran on.  `post(e, tokens)` is applied on the expert's stream
-    (the per-expert projector of the PEP variant).  MM_MOE_STREAMS=0: one after the other on the current stream."""
+    """Every expert tower on the same pixels (reference image_modality_moe.py:156-160), off the host-bound path two ways:
+      * FROZEN towers (the shipped alignment / end2end recipes freeze them; also any no-grad call) are one captured hipGraph per
+        image count: the ~210 launches per ViT-B/32 tower cost the host nothing at replay, and the towers sit on parallel branches
+        of the graph (`_frozen_towers`; MM_MOE_GRAPH=0 disables).  The per-expert projectors (`post`, trainable) stay outside.
+      * trainable towers run side by side, each on ITS OWN HIP stream: at the modality's size the towers are launch-latency-bound
+        chains of short kernels, so E of them side by side take little more than one.  Autograd replays each tower's backward on
+        the stream its forward ran on.  `post(e, tokens)` is applied on the expert's stream.  MM_MOE_STREAMS=0: one after the
+        other on the current stream.
+    Same kernels either way, same results bit for bit."""
     import os
     n = pixels.shape[0]
 
-    def tower(e, expert):
-        hs = expert(pixels).last_hidden_state                             # [n, 1+P, C]
+    def tower(e, expert, px=None):
+        hs = expert(pixels if px is None else px).last_hidden_state                             # [n, 1+P, C]
         T = hs.shape[1]
-        out = Fm.drop_cls(hs.reshape(n * T, -1), n, T)                    # [n, P, C]
-        return post(e, out) if post is not None else out
+        return Fm.drop_cls(hs.reshape(n * T, -1), n, T)                                          # [n, P, C]
 
+    frozen = not torch.is_grad_enabled() or not any(p.requires_grad for ex in experts for p in ex.parameters())
+    if frozen and pixels.is_cuda and os.environ.get("MM_MOE_GRAPH", "1") != "0":
+        outs = _frozen_towers(experts, pixels, tower)
+        return [post(e, o) if post is not None else o for e, o in enumerate(outs)]
     if len(experts) == 1 or not pixels.is_cuda or os.environ.get("MM_MOE_STREAMS", "1") == "0":
-        return [tower(e, ex) for e, ex in enumerate(experts)]
+        return [post(e, tower(e, ex)) if post is not None else tower(e, ex) for e, ex in enumerate(experts)]
     main = torch.cuda.current_stream()
     outs = []
     for e, ex in enumerate(experts):
@@ -153,11 +163,52 @@ def _run_experts(experts, pixels, post=None):
         st.wait_stream(main)                                              # pixels (and the previous step's work) are ready
         with torch.cuda.stream(st):
             o = tower(e, ex)
+            if post is not None:
+                o = post(e, o)
         o.record_stream(main)                                             # produced on `st`, consumed on the compute stream
         outs.append((o, st))
     for _, st in outs:
         main.wait_stream(st)
     return [o for o, _ in outs]
+
+
+def _frozen_towers(experts, pixels, tower):
+    """Captured-graph forward of frozen expert towers: -> list of [n, P, C] token tensors (no autograd history).  One graph per
+    (image count, image size, parameter storage); the pixels are copied into the graph's input buffer, the outputs out of its pool."""
+    key = (tuple(pixels.shape), pixels.dtype, experts[0].embeddings.position_embedding.weight.data_ptr())
+    cache = getattr(experts, "_mm_graphs", None)
+    if cache is None:
+        cache = experts._mm_graphs = {}
+    ent = cache.get(key)
+    if ent is None:
+        with torch.no_grad():
+            static_px = pixels.clone()
+            cur = torch.cuda.current_stream()
+            warm = torch.cuda.Stream()
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm):                                 # lazy initialisation (kernel attributes, id checks) outside capture
+                for _ in range(2):
+                    for e, ex in enumerate(experts):
+                        tower(e, ex, static_px)
+            cur.wait_stream(warm)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                main = torch.cuda.current_stream()
+                res = []
+                for e, ex in enumerate(experts):                          # fork: every tower on its own branch of the graph
+                    st = _expert_stream(pixels.device, e)
+                    st.wait_stream(main)
+                    with torch.cuda.stream(st):
+                        res.append(tower(e, ex, static_px))
+                for e in range(len(experts)):
+                    main.wait_stream(_expert_stream(pixels.device, e))    # join
+        ent = cache[key] = (graph, static_px, res)
+        if len(cache) > 8:                                                # a handful of image counts at most: drop the oldest
+            cache.pop(next(iter(cache)))
+    graph, static_px, res = ent
+    static_px.copy_(pixels)
+    graph.replay()
+    return [o.clone() for o in res]
 
 
 _EXPERT_STREAMS = {}

@@ -170,3 +170,32 @@ def test_shipped_cross_attn_recipes_construct_and_train(tmp_path, pep):
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad.float()).all(), k
     assert float(m.cross_attn.q_proj.weight.grad.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("pep", [False, True])
+def test_frozen_towers_graph_replay_equals_eager(moe, moe_pep, tmp_path, pep, monkeypatch):
+    """Frozen expert towers (the alignment / end2end recipes) run as one captured hipGraph per image count: bit-identical to the
+    eager launches, across replays with new pixels and across image counts; the trainable projector / cross-attention behind them
+    still get their gradients."""
+    meta, w, v = moe_pep if pep else moe
+    m = _build(meta, w, v, "cross_attn", torch.bfloat16, tmp_path)
+    m.freeze_modality_embedder()
+    px = v["pixels"]
+    g = torch.Generator().manual_seed(3)
+    batches = [[px[i] for i in range(px.shape[0])], [torch.randn_like(px[0], generator=g) for _ in range(px.shape[0])],
+               [torch.randn_like(px[0], generator=g) for _ in range(2)], [px[i] for i in range(px.shape[0])]]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MM_MOE_GRAPH", mode)
+        outs[mode] = [m(b).detach().clone() for b in batches]
+    torch.cuda.synchronize()
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs["1"][0], outs["1"][3]) and not torch.equal(outs["1"][0], outs["1"][1])
+    assert len(m.experts._mm_graphs) == 2                                    # two image counts
+    monkeypatch.setenv("MM_MOE_GRAPH", "1")
+    y = m(batches[0])
+    y.float().square().mean().backward()
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert trainable and all(dict(m.named_parameters())[k].grad is not None for k in trainable)
+    assert all(p.grad is None for k, p in m.named_parameters() if k.startswith("experts."))

@@ -39,5 +39,18 @@ for fusion in ("weighted_average", "cross_attn"):
         same = "" if ref is None else f"  output identical to the sequential run: {bool(torch.equal(ref, y))}"
         ref = y.detach().clone() if ref is None else ref
         print(f"{fusion}: E={E} experts (ViT-L/14), n={n} images, MM_MOE_STREAMS={streams}: {ms:.2f} ms fwd+bwd{same}", flush=True)
+    # the shipped alignment / end2end recipes: towers frozen, projector (and cross-attention) trainable
+    m.freeze_modality_embedder()
+    for graph in ("0", "1", "0", "1"):
+        os.environ["MM_MOE_GRAPH"] = graph
+        for it in range(4):
+            if it == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            y = m(px)
+            y.backward(torch.ones_like(y))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 2 * 1e3
+        print(f"{fusion}: frozen towers, MM_MOE_GRAPH={graph}: {ms:.2f} ms fwd (+ projector / fusion bwd)", flush=True)
     del m
     torch.cuda.empty_cache()
