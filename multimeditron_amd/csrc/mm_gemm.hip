@@ -51,6 +51,10 @@ struct GemmArgs {
   // per-token tables rope_cos / rope_sin [M, 64] f32 (0 = no rotation).  The B tile's rows are gathered so that a lane owns
   // columns d and d + 64 of a head (rope_row).
   const float* rope_cos; const float* rope_sin; int rope_cols;
+  // sum of squares of what the epilogue stores (mm_gemm_sumsq, EK = 5): per output tile 16 slots = [column half][wave]; a full
+  // 256x256 tile fills half 0 and zeroes half 1, the half tiles of the last round fill their own half: the slot of a value does
+  // not depend on how the tiles were scheduled (persistent / one tile per workgroup, tail split or not).
+  float* ss;
 };
 constexpr int MM_EPI_SWIGLU_BWD = 1 << 20;   // internal epilogue flag (mm_gemm_swiglu_bwd), not part of the ABI enum
 
@@ -299,9 +303,10 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x
 // keeps the scalar path.
 constexpr unsigned EPI_OOB = 0xFFFFFFFFu;
 
-template <int MREP, int NREP>
-__device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+template <int MREP, int NREP, bool SUMSQ = false>
+__device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int ss_slot = 0) {
   const int l = threadIdx.x & 63;
+  float ssq = 0.f;
   mw = __builtin_amdgcn_readfirstlane(mw);
   nw = __builtin_amdgcn_readfirstlane(nw);
   const int epi = g.epi;
@@ -360,6 +365,12 @@ __device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x
       bf16x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+      if constexpr (SUMSQ) {      // of the bf16 values as stored; rows beyond M carry zeros (their A columns are out of range)
+        if (colb[j] != EPI_OOB) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ssq = __builtin_fmaf((float)o[r], (float)o[r], ssq);
+        }
+      }
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rc, colb[j] == EPI_OOB ? EPI_OOB : rowc + colb[j], 0, 0);
     }
   }
@@ -380,10 +391,19 @@ __device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x
               if (has_bias) v += (float)bias[n + r];
               if (has_res) v += (float)((const bf16*)g.residual)[(int64_t)m * g.ldr + n + r];
               if (has_acc) v += (float)cp[r];
-              cp[r] = (bf16)v;
+              const bf16 ob = (bf16)v;
+              cp[r] = ob;
+              if constexpr (SUMSQ) ssq = __builtin_fmaf((float)ob, (float)ob, ssq);
             }
         }
       }
+    }
+  }
+  if constexpr (SUMSQ) {
+    ssq = wave_sum(ssq);
+    if (l == 0) {
+      g.ss[ss_slot] = ssq;
+      if (ss_slot >= 0 && NREP == 4) g.ss[ss_slot + 8] = 0.f;      // a full tile (NREP == 4) also zeroes its second-half slot
     }
   }
 }
@@ -978,6 +998,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
     else if constexpr (EK == 3) gemm_epilogue_swiglu<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN / 2));
     else if constexpr (EK == 2) gemm_epilogue_ek2<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     else if constexpr (EK == 0) gemm_epilogue_ek0<MREP, NREP>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
+    else if constexpr (EK == 5)
+      gemm_epilogue_plain_pipe<MREP, NREP, true>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN),
+                                                 __builtin_amdgcn_readfirstlane(((m0 / BM_) * g.nbn + n0 / BN_) * 16 + w));
     else gemm_epilogue_plain<MREP, NREP, (BM_ * BN_ <= 128 * 128) && EK == 1, EK == 1>(g, acc, m0 + wm * (BM_ / WGM), n0 + wn * (BN_ / WGN));
     tile = next;
     m0 = nm0;
@@ -1051,6 +1074,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
       }
       if constexpr (EK == 2) gemm_epilogue_ek2<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
       else if constexpr (EK == 0) gemm_epilogue_ek0<MREP, NREPH>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
+      else if constexpr (EK == 5)
+        gemm_epilogue_plain_pipe<MREP, NREPH, true>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN),
+                                                    __builtin_amdgcn_readfirstlane((hm * g.nbn + hn) * 16 + ((int)blockIdx.x & 1) * 8 + w));
       else gemm_epilogue_plain<MREP, NREPH, false, EK == 1>(g, acch, hm0 + wm * (BM_ / WGM), hn0 + wn * (BNH / WGN));
     }
   }
@@ -1615,29 +1641,51 @@ static int sumsq_blocks(int64_t M, int64_t N) {
   const int64_t v = (M * N / 4 + 255) / 256;
   return (int)(v < 1 ? 1 : (v > 1024 ? 1024 : v));
 }
+// slots of the in-epilogue form: 16 per 256x256 output tile
+static int64_t sumsq_tile_slots(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) * 16; }
+
 extern "C" int mm_gemm_sumsq_slots(int dtype, int layout, int M, int N, int K, int64_t* slots) {
   if (!slots || M <= 0 || N <= 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;
   if (dtype != MM_BF16) return MM_ERR_UNSUPPORTED;
-  *slots = sumsq_blocks(M, N);
+  const int64_t a = sumsq_blocks(M, N), b = sumsq_tile_slots(M, N);
+  *slots = a > b ? a : b;                      // whichever form a call takes fits
   return MM_OK;
 }
 
+// Round 3: the sum is taken INSIDE the epilogue again, but in an instantiation of its own (EK = 5, the TN 256x256 kernel the
+// decoder's weight gradients run): round 2's first cut had the extra FMA inlined into the shared epilogue, where it cost every
+// other GEMM 1.6 %; the second cut (GEMM + a reduction pass over C) was neutral against the gradient-norm sweep it replaces.
+// Other shapes / layouts keep the two-pass form.  Either way partials[0 .. n) are OVERWRITTEN (n <= mm_gemm_sumsq_slots).
 extern "C" int mm_gemm_sumsq(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
                              int ldc, int epilogue, float* partials, int64_t capacity, void* stream) {
   if (M < 0 || N < 0 || K < 0 || layout < 0 || layout > 2) return MM_ERR_ARG;
   if (dtype != MM_BF16) return MM_ERR_UNSUPPORTED;
   if (!A || !B || !C || !partials || capacity <= 0 || (epilogue & ~MM_EPI_ACCUMULATE)) return MM_ERR_ARG;
   if (M == 0 || N == 0) return hipMemsetAsync(partials, 0, (size_t)capacity * sizeof(float), (hipStream_t)stream) == hipSuccess ? MM_OK : MM_ERR_LAUNCH;
-  const int nb = sumsq_blocks(M, N);
-  if (capacity < nb) return MM_ERR_ARG;
+  int64_t need = 0;
+  mm_gemm_sumsq_slots(dtype, layout, M, N, K, &need);
+  if (capacity < need) return MM_ERR_ARG;
   GemmArgs g{M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, epilogue};
+  static const bool in_epi = [] { const char* e = getenv("MM_SUMSQ_EPILOGUE"); return !e || e[0] != '0'; }();
+  if (in_epi && layout == MM_GEMM_TN) {
+    g.ss = partials;
+    const int rc = gemm_launch(g, dtype, layout, (hipStream_t)stream);
+    if (rc == MM_OK) {                         // slots beyond the tiles' (the two-pass count may be larger) must read zero
+      const int64_t used = sumsq_tile_slots(M, N);
+      if (need > used && hipMemsetAsync(partials + used, 0, (size_t)(need - used) * sizeof(float), (hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;
+      return MM_OK;
+    }
+    if (rc != MM_ERR_UNSUPPORTED) return rc;
+    g.ss = nullptr;
+  }
+  const int nb = sumsq_blocks(M, N);
   const int rc = gemm_launch(g, dtype, layout, (hipStream_t)stream);
   if (rc != MM_OK) return rc;
   hipLaunchKernelGGL(sumsq2d_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16*)C, M, N, ldc, partials);
+  if (need > nb && hipMemsetAsync(partials + nb, 0, (size_t)(need - nb) * sizeof(float), (hipStream_t)stream) != hipSuccess) return MM_ERR_LAUNCH;
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
-
 
 // ---- decode-step entry points (KV-cache decode of generate, reference model.py:595-602: M = batch <= 16 rows) ------------------
 static int skinny_common(int dtype, int M, int K, const void* X, int ldx, const void* W, int ldw, int64_t wrows) {
@@ -1775,7 +1823,11 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
     else MM_LAUNCH_ONE(AKC, BKC, 256, 256, 2, 2, 8, EK);                                                                 \
   } while (0)
       // epilogue kind = kernel instantiation: the SwiGLU ones exist for the layout their entry point uses only
-      if (g.rope_cols) {                                                  // mm_gemm_rope_fwd: NT, 256x256
+      if (g.ss) {                                                         // mm_gemm_sumsq in the epilogue: TN, 256x256
+        if (layout != MM_GEMM_TN || variant != 2 || (epilogue & ~MM_EPI_ACCUMULATE)) return MM_ERR_UNSUPPORTED;
+        if (g_opt_issue_waves == 4) MM_LAUNCH_ONE(false, false, 256, 256, 2, 2, 4, 5);
+        else MM_LAUNCH_ONE(false, false, 256, 256, 2, 2, 8, 5);
+      } else if (g.rope_cols) {                                           // mm_gemm_rope_fwd: NT, 256x256
         if (layout != MM_GEMM_NT) return MM_ERR_ARG;
         if (g_opt_issue_waves == 4) MM_LAUNCH_ONE(true, true, 256, 256, 2, 2, 4, 4);
         else MM_LAUNCH_ONE(true, true, 256, 256, 2, 2, 8, 4);
@@ -1799,6 +1851,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
 #undef MM_LAUNCH_ONE
 #undef MM_LAUNCH_DMA
     } else {
+      if (g.ss) return MM_ERR_UNSUPPORTED;
       g.nbm = (M + BM - 1) / BM;
       g.nbn = (N + BN - 1) / BN;
       const int64_t nwg = (int64_t)g.nbm * g.nbn;

@@ -721,6 +721,36 @@ def test_adamw_and_gradnorm(K, dtype):
     assert rel(pg.float(), ref_p.detach()) < (1e-5 if dtype == torch.float32 else 5e-3)
 
 
+@pytest.mark.parametrize("M,N,Kd", [(4096, 4096, 512), (4000, 3304, 320), (6144, 4096, 256), (520, 296, 128)])
+@pytest.mark.parametrize("persist", [1, 0])
+def test_gemm_sumsq_in_epilogue(K, M, N, Kd, persist):
+    """mm_gemm_sumsq on weight-gradient shapes (TN): the 256x256 kernel takes the sum of squares of the bf16 values it stores inside
+    its epilogue (EK = 5; per-tile slots, no atomics), smaller problems take GEMM + a reduction pass.  C must equal the plain GEMM's
+    bit for bit, sum(partials) the sum of squares of C (overwrite and accumulate), identically run to run and whichever way the tiles
+    were scheduled (persistent grid with the half-tile tail, or one tile per workgroup)."""
+    from multimeditron_amd._lib import GEMM_TN, lib
+    dy = rnd((Kd, M), torch.bfloat16, 401).cuda()           # A = dy^T: [K, M]
+    x = rnd((Kd, N), torch.bfloat16, 402).cuda()            # B = x:    [K, N]
+    ref = K.gemm(GEMM_TN, dy, x, M, N, Kd)
+    slots = torch.full((K.gemm_sumsq_slots(GEMM_TN, M, N, Kd),), float("nan"), device="cuda")
+    assert lib().mm_set_option(b"gemm_persist", persist) == 0
+    try:
+        out = torch.empty_like(ref)
+        K.gemm(GEMM_TN, dy, x, M, N, Kd, out=out, sumsq=slots)
+        s1 = slots.clone()
+        K.gemm(GEMM_TN, dy, x, M, N, Kd, out=out, sumsq=slots)
+        assert torch.equal(out, ref) and torch.equal(s1, slots) and bool(torch.isfinite(slots).all())
+        want = float((ref.double() ** 2).sum())
+        assert abs(float(slots.double().sum()) - want) < 1e-5 * want
+        K.gemm(GEMM_TN, dy, x, M, N, Kd, out=out, accumulate=True, sumsq=slots)       # C = ref + ref (rounded)
+        two = (ref.float() * 2).to(torch.bfloat16)
+        assert torch.equal(out, two)
+        want2 = float((two.double() ** 2).sum())
+        assert abs(float(slots.double().sum()) - want2) < 1e-5 * want2
+    finally:
+        lib().mm_set_option(b"gemm_persist", 1)
+
+
 def test_adamw_split_master_equals_fp32_master(K):
     """mm_adamw_step_split keeps the fp32 master as (bf16 parameter, int16 remainder): over several clipped steps the bf16 parameters
     must equal those of mm_adamw_step with a separate fp32 master BIT FOR BIT, the joined master must stay within one fp32 ulp of it
