@@ -41,14 +41,15 @@ PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak of gfx950 (MI355X_MICROA
 PEAK_HBM_GBS = 8000.0
 
 
-def flops_per_sample(llm, vis, S, n_img, vocab, hidden_proj):
+def flops_per_sample(llm, vis, S, n_img, vocab, hidden_proj, lm_head_rows=None):
     """Algorithmic forward FLOPs per sample: 2*params*tokens for linears, 4*T^2*d*L attention (causal
-    halved).  fwd+bwd (FULL) = 3x."""
+    halved).  fwd+bwd (FULL) = 3x.  lm_head_rows: rows per sample that go through lm_head (default: all S, as HF computes;
+    the Trainer runs lm_head on the labelled rows only -- EXECUTED flops count those)."""
     H, I, L = llm["hidden_size"], llm["intermediate_size"], llm["num_hidden_layers"]
     hd = llm["head_dim"]
     qo, kv = llm["num_attention_heads"] * hd, llm["num_key_value_heads"] * hd
-    lin = L * (H * (qo + 2 * kv) + qo * H + 3 * H * I) + H * vocab
-    f = 2.0 * lin * S + 0.5 * 4.0 * S * S * qo * L
+    lin = L * (H * (qo + 2 * kv) + qo * H + 3 * H * I)
+    f = 2.0 * lin * S + 2.0 * H * vocab * (S if lm_head_rows is None else lm_head_rows) + 0.5 * 4.0 * S * S * qo * L
     Dv, Iv, Lv = vis["hidden_size"], vis["intermediate_size"], vis["num_hidden_layers"]
     P = (vis["image_size"] // vis["patch_size"]) ** 2
     T = P + (0 if vis.get("kind") == "siglip" else 1)       # SigLIP has no CLS token
@@ -457,6 +458,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     fps = 3.0 * flops_per_sample(llm, vis, S, n_img, vocab, llm["hidden_size"]) if args.mode == "FULL" else None
+    rows = getattr(batch["labels"], "_mm_loss_rows", None) if trainer.loss_rows_only else None
+    fps_exec = fps
+    if fps is not None and rows is not None:              # lm_head + loss ran on the labelled rows only: count what was executed
+        fps_exec = 3.0 * flops_per_sample(llm, vis, S, n_img, vocab, llm["hidden_size"], lm_head_rows=rows.n / B)
     value = world * B * args.steps / elapsed
     out = {"metric": f"image-text samples/sec/node fwd+bwd, {METRIC_MODELS[args.workload]} bf16", "value": round(value, 4), "unit": "samples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -477,8 +482,12 @@ def main():
     r = measure_gemm_roofline(trainer, batch) if not args.no_roofline else None
     if rank == 0:
         if fps is not None:
-            step_tf = value / world * fps / 1e12
-            out["config"]["flops_per_sample_fwd_bwd"] = fps
+            step_tf = value / world * fps_exec / 1e12
+            out["config"]["flops_per_sample_fwd_bwd"] = fps_exec
+            if rows is not None:
+                out["config"]["loss_rows"] = (f"final norm, lm_head and cross-entropy on the {rows.n} of {rows.total} rows whose shifted label is "
+                                              f"not -100 (same loss and gradients; MM_LOSS_ROWS=0 computes every row as HF does: "
+                                              f"{fps:.6g} flops/sample); whole_step_* count the executed flops")
         roof = None
         if r is not None:
             roof = {"bound": "mfma", "kernel": "gemm_bf16_dma_kernel (NT/NN/TN; every bf16 mm_gemm launch of the step)", "achieved": round(r["achieved_tflops"], 2), "peak": PEAK_BF16_TFLOPS,

@@ -146,6 +146,11 @@ int mm_bcast_add(int dtype, const void* x, const void* b, int n, int64_t L, void
 int mm_head_pad(int dtype, const void* src, int64_t rows, int nheads, int d, int dpad, void* dst, int inverse, void* stream);
 int mm_drop_cls_fwd(int dtype, const void* src, int n, int P, int D, void* dst, void* stream);
 int mm_drop_cls_bwd(int dtype, const void* ddst, int n, int P, int D, void* dsrc, void* stream);
+/* Loss rows (HF:loss/loss_utils.py:36-71 ignores labels == -100; llama modeling's lm_head + loss_function call): the training
+ * step computes the final norm, lm_head and the loss only on the rows that carry a label.  dst[r, :D] = src[map[r], :D], or
+ * zeros where map[r] < 0 (or >= n_src).  Forward: map = indices of the labelled rows; backward: map = the inverse map.       */
+int mm_rows_select(int dtype, const void* src, int64_t ld_src, const int* map, int n_src, int n_dst, int D, void* dst,
+                   int64_t ld_dst, void* stream);
 
 /* ---- norms ------------------------------------------------------------------------------------------
  * RMSNorm: HF:llama:53-70.  rstd[M] f32 is saved for backward.                                            */

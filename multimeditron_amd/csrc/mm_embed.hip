@@ -463,6 +463,48 @@ extern "C" int mm_drop_cls_bwd(int dtype, const void* ddst, int n, int P, int D,
   return drop_cls_launch<true>(dtype, ddst, n, P, D, dsrc, stream);
 }
 
+// ---- loss rows: the rows of the last hidden state whose (shifted) label is not -100 ------------------------------------
+// HF computes logits for every position and lets cross_entropy ignore the -100 ones (HF:loss/loss_utils.py:36-71); the loss
+// and every gradient depend only on the labelled rows (an ignored row's dlogits are exactly zero), so the training step runs
+// the final norm, lm_head and the loss on those rows alone.  One kernel serves both directions: dst[r] = src[map[r]], or a
+// zero row where map[r] < 0 (forward: map = the labelled rows' indices; backward: map = the inverse, -1 at ignored rows).
+namespace {
+template <typename T>
+__global__ void rows_select_kernel(const T* src, int64_t ld_src, const int* map, int n_src, int n_dst, int D, T* dst, int64_t ld_dst) {
+  constexpr int VN = Vec16<T>::N;
+  const int per_row = D / VN;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_dst * per_row) return;
+  const int c = (int)(i % per_row) * VN;
+  const int r = (int)(i / per_row);
+  const int m = map[r];
+  Vec16<T> v;
+  if (m >= 0 && m < n_src) {
+    v = *(const Vec16<T>*)(src + (int64_t)m * ld_src + c);
+  } else {
+#pragma unroll
+    for (int k = 0; k < VN; ++k) v.set(k, 0.f);
+  }
+  *(Vec16<T>*)(dst + (int64_t)r * ld_dst + c) = v;
+}
+}  // namespace
+
+extern "C" int mm_rows_select(int dtype, const void* src, int64_t ld_src, const int* map, int n_src, int n_dst, int D, void* dst,
+                              int64_t ld_dst, void* stream) {
+  if (!src || !dst || !map || n_src < 0 || n_dst < 0 || D <= 0) return MM_ERR_ARG;
+  if (n_dst == 0) return MM_OK;
+  const int vn = dtype == MM_BF16 ? 8 : 4;
+  if (D % vn || ld_src % vn || ld_dst % vn || ld_src < D || ld_dst < D || !mm_aligned16(src) || !mm_aligned16(dst)) return MM_ERR_ALIGN;
+  const int64_t total = (int64_t)n_dst * (D / vn);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == MM_BF16)
+    hipLaunchKernelGGL(rows_select_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld_src, map, n_src, n_dst, D, (bf16*)dst, ld_dst);
+  else
+    hipLaunchKernelGGL(rows_select_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, ld_src, map, n_src, n_dst, D, (float*)dst, ld_dst);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
 // ---- plug-in towers: learned positions without a CLS row, heads padded to a width the MFMA attention supports ----------
 namespace {
 template <typename T>

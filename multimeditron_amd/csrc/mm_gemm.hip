@@ -341,6 +341,7 @@ __device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x
     }
   };
   request(0, 0);
+  const unsigned row_lim = rows > 0 ? (unsigned)((rows < MREP * 16 ? rows : MREP * 16) * g.ldc) * 2u : 0u;      // wave-uniform: byte offset of the first row >= M
 #pragma unroll
   for (int i = 0; i < MREP; ++i) {
     if (i + 1 < MREP) request(i + 1, (i + 1) & 1);
@@ -365,8 +366,9 @@ __device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x
       bf16x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-      if constexpr (SUMSQ) {      // of the bf16 values as stored; rows beyond M carry zeros (their A columns are out of range)
-        if (colb[j] != EPI_OOB) {
+      if constexpr (SUMSQ) {      // of the bf16 values as stored; a row >= M or a column >= N holds whatever the operand tiles'
+                                  // neighbours hold (only the STORE is range-checked), so both are masked here
+        if (colb[j] != EPI_OOB && rowc < row_lim) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) ssq = __builtin_fmaf((float)o[r], (float)o[r], ssq);
         }

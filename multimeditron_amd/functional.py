@@ -780,5 +780,48 @@ class CausalLMLossFn(torch.autograd.Function):
         return d, None, None
 
 
+class LossRows:
+    """The rows of a [B*S] batch whose SHIFTED label is not -100, as the host knows them (built where the labels still are a
+    host tensor: train/prefetch.py, or CausalLM.forward for host labels): `idx` int32 [n] ascending, `inv` int32 [B*S] (-1 at
+    ignored rows), `labels` int64 [n] (the shifted labels of those rows), all on the device."""
+    __slots__ = ("idx", "inv", "labels", "n", "total")
+
+    def __init__(self, idx, inv, labels, n, total):
+        self.idx, self.inv, self.labels, self.n, self.total = idx, inv, labels, int(n), int(total)
+
+    @staticmethod
+    def host_parts(labels_host: torch.Tensor):
+        """-> (idx int32 [n], inv int32 [B*S], shifted labels int64 [n]) on the host; HF:loss/loss_utils.py:52-56 shift."""
+        shift = torch.nn.functional.pad(labels_host, (0, 1), value=-100)[..., 1:].reshape(-1)
+        keep = shift != -100
+        idx = torch.nonzero(keep).reshape(-1).to(torch.int32)
+        inv = torch.full((shift.numel(),), -1, dtype=torch.int32)
+        inv[keep] = torch.arange(idx.numel(), dtype=torch.int32)
+        return idx, inv, shift[keep].contiguous()
+
+    @classmethod
+    def from_host_labels(cls, labels_host, device):
+        idx, inv, lab = cls.host_parts(labels_host)
+        return cls(idx.to(device), inv.to(device), lab.to(device), idx.numel(), inv.numel())
+
+
+class RowsSelectFn(torch.autograd.Function):
+    """y = x[rows.idx]; backward scatters dy back into a [B*S, H] gradient with exact zeros at the ignored rows."""
+
+    @staticmethod
+    def forward(ctx, x2d, rows):
+        ctx.rows = rows
+        return K.rows_select(x2d, rows.idx, rows.n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows = ctx.rows
+        return K.rows_select(dy.contiguous(), rows.inv, rows.total), None
+
+
+def rows_select(x2d, rows):
+    return RowsSelectFn.apply(x2d, rows)
+
+
 def causal_lm_loss(logits2d, V, shift_labels):
     return CausalLMLossFn.apply(logits2d, V, shift_labels)

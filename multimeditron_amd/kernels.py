@@ -349,6 +349,15 @@ def drop_cls_bwd(dy):
     return out
 
 
+def rows_select(src2d, row_map, n_dst):
+    """dst[r] = src2d[row_map[r]] (zeros where row_map[r] < 0); row_map int32 on the device, n_dst known to the host."""
+    D = src2d.shape[1]
+    assert row_map.dtype == torch.int32 and row_map.is_contiguous() and row_map.numel() >= n_dst and src2d.stride(1) == 1
+    out = torch.empty((n_dst, D), dtype=src2d.dtype, device=src2d.device)
+    call("mm_rows_select", dt(src2d), _p(src2d), src2d.stride(0), _p(row_map), src2d.shape[0], n_dst, D, _p(out), D, _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ norms
 def rmsnorm_fwd(x2d, w, eps):
     M, H = x2d.shape

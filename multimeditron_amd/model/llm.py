@@ -290,6 +290,9 @@ class CausalLM(nn.Module):
         dev = inputs_embeds.device
         cache = past_key_values
         past = cache[0].len if cache else 0
+        rows = kwargs.get("loss_rows")
+        if rows is not None and (labels is None or cache or use_cache or logits_to_keep or rows.n == 0 or rows.total != B * S):
+            rows = None                                      # anything but a plain training forward: every position's logits
         if use_cache and cache is None:
             cache = self.new_cache(B, S + int(kwargs.get("max_new_tokens", 512)))
         if position_ids is None:
@@ -316,6 +319,11 @@ class CausalLM(nn.Module):
         else:
             for i, layer in enumerate(layers):
                 x = layer(x, cos, sin, key_mask, B, S, cache=cache[i] if cache else None)
+            if rows is not None:
+                # training step (Trainer.compute_loss hands over `loss_rows`): the loss and every gradient depend only on the
+                # rows whose shifted label is not -100 (HF:loss/loss_utils.py:36-71 ignores the others; their dlogits are exactly
+                # zero), so the final norm, lm_head and the loss run on those rows alone; `logits` is then not returned
+                x = Fm.rows_select(x, rows)
             x, _ = self.model.norm(x)
         V = self.config.vocab_size
         if logits_to_keep:
@@ -325,6 +333,10 @@ class CausalLM(nn.Module):
             Sk = S
         logits2d = self.lm_head(x, ldc_pad=True)                 # [B*Sk, V] view, row stride padded to 64
         loss = None
+        if rows is not None:
+            loss = Fm.causal_lm_loss(logits2d, V, rows.labels)
+            out = CausalLMOutput(loss=loss, logits=None, past_key_values=None)
+            return out if return_dict else (loss, None, None)
         if labels is not None:
             shift = torch.nn.functional.pad(labels.to(dev), (0, 1), value=-100)[..., 1:].reshape(-1).contiguous()
             loss = Fm.causal_lm_loss(logits2d, V, shift)

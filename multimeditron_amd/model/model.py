@@ -429,6 +429,7 @@ class MultiModalModelForCausalLM(nn.Module):
             logger.warning(f"Truncating input to {msl} tokens.")
             inputs_embeds = inputs_embeds[:, :msl, :]
             labels = labels[:, :msl] if labels is not None else None
+            kwargs.pop("loss_rows", None)                    # built from the untruncated labels
             attention_mask = attention_mask[:, :msl] if attention_mask is not None else None
             position_ids = position_ids[:, :msl] if position_ids is not None else None
         with trace_range("decoder+loss"):

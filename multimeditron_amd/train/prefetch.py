@@ -10,6 +10,8 @@ batches and, while step n runs, stages batch n+1:
   * pinned buffers are kept and reused per slot (`depth` slots; a slot is reused only after its copy event has completed);
   * `__next__` makes the compute stream wait for the slot's copy event, so `ImageModality.forward`'s `.to(device)` finds a
     device tensor and becomes a no-op;
+  * `labels` carries `_mm_loss_rows` (functional.LossRows: which rows have a shifted label != -100, computed on the host
+    copy), which lets the Trainer run the final norm, lm_head and the loss on the labelled rows only;
   * `attention_mask` carries `_mm_all_ones` (computed on the host copy, where it is free): an all-ones mask masks nothing,
     and the decoder then skips the key-mask path exactly as HF's `_ignore_causal_mask_sdpa` does.
 
@@ -76,6 +78,11 @@ class DevicePrefetcher:
                     d = self._h2d(slot, k, v)
                     if k == "attention_mask":
                         d._mm_all_ones = bool(v.all()) if not v.is_cuda else getattr(v, "_mm_all_ones", False)
+                    if k == "labels" and not v.is_cuda:
+                        from ..functional import LossRows               # which rows carry a label: free on the host copy
+                        idx, inv, lab = LossRows.host_parts(v)
+                        d._mm_loss_rows = LossRows(self._h2d(slot, "loss_rows.idx", idx), self._h2d(slot, "loss_rows.inv", inv),
+                                                   self._h2d(slot, "loss_rows.labels", lab), idx.numel(), inv.numel())
                     out[k] = d
                 elif k in batch:
                     out[k] = v
@@ -138,6 +145,9 @@ def _iter_tensors(obj):
     if torch.is_tensor(obj):
         if obj.is_cuda:
             yield obj
+            rows = getattr(obj, "_mm_loss_rows", None)
+            if rows is not None:
+                yield from (rows.idx, rows.inv, rows.labels)
     elif isinstance(obj, dict):
         for v in obj.values():
             yield from _iter_tensors(v)

@@ -81,8 +81,11 @@ class MultimodalTrainer:
                  gradient_accumulation_steps: int = 1, max_steps: int = 0, min_lr: Optional[float] = None, warmup_steps: int = 0,
                  bucket_mb: int = 256, process_group=None, data_collator=None, train_dataset=None,
                  overlap_optimizer: bool = True, lr_scheduler_type: str = "cosine_with_min_lr", per_device_train_batch_size: int = 4,
-                 shard_optimizer: Optional[bool] = None):
+                 shard_optimizer: Optional[bool] = None, loss_rows_only: Optional[bool] = None):
         self.model = model
+        # compute_loss: final norm, lm_head and the loss on the labelled rows only (same loss, same gradients; MM_LOSS_ROWS=0 or
+        # loss_rows_only=False computes every position's logits as HF does)
+        self.loss_rows_only = (os.environ.get("MM_LOSS_ROWS", "1") != "0") if loss_rows_only is None else bool(loss_rows_only)
         self.training_mode = TrainingMode(training_mode)
         self.lr, self.wd, self.betas, self.eps = learning_rate, weight_decay, betas, eps
         self.max_grad_norm = max_grad_norm
@@ -347,8 +350,18 @@ class MultimodalTrainer:
     # ------------------------------------------------------------------ reference surface
     def compute_loss(self, model, inputs, return_outputs=False, **kwargs):
         """reference trainer.py:91-118"""
-        outputs = model(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"), labels=inputs["labels"],
-                        position_ids=inputs["position_ids"], processed_multimodal_inputs=inputs["processed_multimodal_inputs"])
+        labels = inputs["labels"]
+        rows = None
+        if self.loss_rows_only and model.training:
+            # the step needs the loss, not the logits: final norm, lm_head and cross-entropy on the labelled rows only (exactly
+            # the rows HF's loss keeps; functional.LossRows).  Known without a device sync for host labels / prefetched batches.
+            rows = getattr(labels, "_mm_loss_rows", None)
+            if rows is None and torch.is_tensor(labels) and not labels.is_cuda:
+                from ..functional import LossRows
+                rows = LossRows.from_host_labels(labels, self.flat.device)
+        outputs = model(input_ids=inputs["input_ids"], attention_mask=inputs.get("attention_mask"), labels=labels,
+                        position_ids=inputs["position_ids"], processed_multimodal_inputs=inputs["processed_multimodal_inputs"],
+                        loss_rows=rows)
         return (outputs.loss, outputs) if return_outputs else outputs.loss
 
     # ------------------------------------------------------------------ one optimisation step

@@ -33,6 +33,9 @@ def to_device(batch, device="cuda"):
     for k, v in batch.items():
         if torch.is_tensor(v):
             out[k] = v.to(device)
+            if k == "labels" and not v.is_cuda and str(device) != "cpu":      # what train/prefetch.py attaches to a staged batch
+                from multimeditron_amd.functional import LossRows
+                out[k]._mm_loss_rows = LossRows.from_host_labels(v, device)
         elif k == "processed_multimodal_inputs":
             out[k] = {"batch_idx": {t: x.to(device) for t, x in v["batch_idx"].items()},
                       "token_range": {t: x.to(device) for t, x in v["token_range"].items()},

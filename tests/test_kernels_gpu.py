@@ -885,3 +885,31 @@ def test_linear_gelu_keeps_preactivation_bit_identical(K, act_name, shape):     
     torch.cuda.synchronize()
     assert torch.equal(pre, pre_ref)
     assert torch.equal(y, y_ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rows_select_both_directions(K, dtype):
+    """mm_rows_select: gather of the labelled rows (forward) and the scatter back with zero rows (backward), against torch
+    indexing -- bit-exact (a copy); strided source rows; the host-side index builder against HF's shift-then-ignore rule."""
+    from multimeditron_amd.functional import LossRows
+    g0 = torch.Generator().manual_seed(11)
+    B, S, H = 3, 37, 64
+    labels = torch.randint(0, 1000, (B, S), generator=g0)
+    labels[torch.rand(B, S, generator=g0) < 0.4] = -100
+    labels[1, :] = -100                                                   # a sample without any label
+    rows = LossRows.from_host_labels(labels, "cuda")
+    shift = torch.nn.functional.pad(labels, (0, 1), value=-100)[..., 1:].reshape(-1)
+    keep = (shift != -100).nonzero().reshape(-1)
+    assert rows.n == keep.numel() and rows.total == B * S
+    assert torch.equal(rows.idx.cpu().long(), keep) and torch.equal(rows.labels.cpu(), shift[keep])
+    inv = rows.inv.cpu().long()
+    assert torch.equal(inv[keep], torch.arange(keep.numel())) and int((inv < 0).sum()) == B * S - keep.numel()
+    wide = rnd((B * S, H + 16), dtype, 12).cuda()
+    x = wide[:, :H]                                                       # row stride H + 16
+    y = K.rows_select(x, rows.idx, rows.n)
+    assert torch.equal(y, x[keep.cuda()])
+    dy = rnd((rows.n, H), dtype, 13).cuda()
+    dx = K.rows_select(dy, rows.inv, rows.total)
+    want = torch.zeros(B * S, H, dtype=dtype, device="cuda")
+    want[keep.cuda()] = dy
+    assert torch.equal(dx, want)

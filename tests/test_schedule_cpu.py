@@ -55,3 +55,20 @@ def test_weight_decay_grouping_equals_hf_trainer(golden_dir, tmp_path):
     assert ours == want, (sorted(ours - want)[:5], sorted(want - ours)[:5])
     assert "modalities_with_projection.0.feature_extractor.vision_model.embeddings.class_embedding" in ours
     assert not any(re.search(r"bias|norm", n.lower()) for n in ours)
+
+
+def test_loss_rows_follow_hf_shift_and_ignore_rule():
+    """functional.LossRows.host_parts: the rows the Trainer runs lm_head on are exactly the rows HF's loss keeps
+    (HF:loss/loss_utils.py:52-56: labels shifted left by one, the last position and every -100 ignored)."""
+    import torch
+    from multimeditron_amd.functional import LossRows
+    labels = torch.tensor([[5, -100, 7, 8], [-100, -100, -100, 3], [-100, -100, -100, -100]])
+    idx, inv, lab = LossRows.host_parts(labels)
+    # sample 0: position 0 predicts -100 (ignored), 1 -> 7, 2 -> 8, 3 -> nothing; sample 1: position 2 -> 3; sample 2: none
+    assert idx.tolist() == [1, 2, 6] and lab.tolist() == [7, 8, 3]
+    assert inv.tolist() == [-1, 0, 1, -1, -1, -1, 2, -1, -1, -1, -1, -1]
+    logits = torch.randn(12, 11)
+    full = torch.nn.functional.cross_entropy(logits, torch.nn.functional.pad(labels, (0, 1), value=-100)[..., 1:].reshape(-1),
+                                             ignore_index=-100)
+    rows = torch.nn.functional.cross_entropy(logits[idx.long()], lab)
+    assert abs(float(full) - float(rows)) < 1e-6

@@ -12,14 +12,17 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("name", ["tiny_clip_llama", "tiny_clip_qwen2"])
 @pytest.mark.parametrize("mode", ["FULL", "ALIGNMENT", "END2END", "LM_ONLY"])
-def test_training_steps_match_oracle(golden_dir, tmp_path, name, mode):
+@pytest.mark.parametrize("loss_rows", [True, False], ids=["labelled_rows", "all_rows"])
+def test_training_steps_match_oracle(golden_dir, tmp_path, name, mode, loss_rows):
+    """loss_rows: final norm + lm_head + loss on the labelled rows only (the Trainer's default) or on every row as HF computes
+    them -- the oracle always does the latter; both must meet the same bounds."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
     meta, w, v = R.load_golden(name, golden_dir)
     model = build_from_golden(meta, w, tmp_path, "float32")
     tr = MultimodalTrainer(model, training_mode=TrainingMode[mode], learning_rate=1e-3, weight_decay=0.01, betas=(0.9, 0.95),
-                           max_grad_norm=1.0, gradient_accumulation_steps=1)
+                           max_grad_norm=1.0, gradient_accumulation_steps=1, loss_rows_only=loss_rows)
     cases = ["right", "textonly", "interleaved4"]     # the text-only step leaves the vision tower without gradients
     losses = [float(tr.training_step(to_device(R.golden_batch(v, c)))) for c in cases]
     tr.synchronize()
@@ -181,3 +184,36 @@ def test_resume_is_bit_exact(golden_dir, tmp_path, dtype):
         for (k1, p1), (k2, p2) in zip(m_a.named_parameters(), m_c.named_parameters()):     # Adam divides by sqrt(v): an element whose
             assert k1 == k2 and float((p1 - p2).norm()) <= 1e-4 * float(p1.norm()) + 1e-7, k1   # gradient is rounding noise may move by ~lr
         assert float((t_a.master - t_c.master).norm()) < 1e-4 * float(t_a.master.norm())
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
+def test_loss_on_labelled_rows_equals_loss_on_all_rows(golden_dir, tmp_path, dtype):
+    """Trainer.compute_loss with `loss_rows` (final norm, lm_head and cross-entropy on the rows whose shifted label is not -100)
+    against the HF form (every row's logits, the loss ignores the -100 rows): same loss and the same gradient for EVERY parameter.
+    fp32: <= 1e-6 relative (the lm_head wgrad sums the same products with the zero rows left out); bf16: <= 2e-3 of the gradient's
+    norm (the K order of the wgrad changes where its partial sums round)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
+    meta, w, v = R.load_golden("tiny_clip_llama", golden_dir)
+    got = {}
+    for rows in (True, False):
+        model = build_from_golden(meta, w, tmp_path / f"rows{int(rows)}", dtype)
+        tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=0.0, weight_decay=0.0, max_grad_norm=1.0,
+                               loss_rows_only=rows, overlap_optimizer=False)
+        losses = []
+        for case in ("right", "interleaved4"):
+            b = to_device(R.golden_batch(v, case))
+            assert (b["labels"]._mm_loss_rows.n < b["labels"].numel()) and b["labels"]._mm_loss_rows.n > 0
+            losses.append(float(tr.training_step(b)))
+            tr.synchronize()
+            torch.cuda.synchronize()
+            losses.append(torch.cat([tr.flat.grad[s0:e0].detach().float() for s0, e0, _ in tr.ranges]))
+        got[rows] = losses
+    tol_loss, tol_grad = (1e-6, 1e-6) if dtype == "float32" else (2e-3, 2e-3)
+    for a, b in zip(got[True], got[False]):
+        if isinstance(a, float):
+            assert abs(a - b) <= tol_loss * max(1.0, abs(b)), (a, b)
+        else:
+            assert float((a - b).norm()) <= tol_grad * float(b.norm()), float((a - b).norm() / b.norm())
+            assert float(b.norm()) > 0
