@@ -345,6 +345,14 @@ int mm_fill_zero(void* p, int64_t bytes, void* stream);
  * tr_read: img = 4096 bf16 copied to LDS; lane l reads at byte address addr[l]; out[l*4+j] = its j-th element.
  * mfma: shape 32 -> v_mfma_f32_32x32x16_bf16 (out 64x16 f32), 16 -> v_mfma_f32_16x16x32_bf16 (out 64x4 f32);
  *       a/b = 64 lanes x 8 bf16 fragments.                                                                         */
+/* Streams restricted to a subset of the CUs (no reference counterpart: the reference leaves kernel placement to PyTorch).  `mask`:
+ * bit i of word i / 32 enables CU i (hipExtStreamCreateWithCUMask).  The Trainer runs AdamW and the deferred weight-gradient GEMMs
+ * on such streams so that the small kernels of the modality tower they overlap always find free CUs.  mm_debug_cu_probe: where
+ * the workgroups of a launch on `stream` ran (XCC_ID and HW_ID registers), for tools/cumask_probe.py.                            */
+int mm_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream);
+int mm_stream_destroy(void* stream);
+int mm_device_cu_count(void);
+int mm_debug_cu_probe(void* out_u32, int n_wg, int threads, int64_t spin_ticks, void* stream);
 int mm_debug_tr_read(const void* img_bf16_4096, const void* lane_byte_addr_i32_64, void* out_bf16_256, void* stream);
 int mm_debug_mfma(int shape, const void* a_frag_bf16_512, const void* b_frag_bf16_512, void* out_f32, void* stream);
 

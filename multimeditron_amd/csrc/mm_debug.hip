@@ -42,3 +42,45 @@ extern "C" int mm_debug_mfma(int shape, const void* a_frag_bf16_512, const void*
   MM_CHECK_LAUNCH();
   return MM_OK;
 }
+
+// ---- streams restricted to a subset of the CUs (hipExtStreamCreateWithCUMask) ----------------------------------------
+// The training step runs two HBM- / MFMA-saturating bursts BESIDE a latency-bound chain of small kernels (AdamW beside the next
+// ViT forward; the deferred weight-gradient GEMMs beside the ViT backward).  A burst that may use every CU leaves the chain's
+// workgroups waiting for a CU to drain (a 256x256 GEMM tile holds its CU for ~220 us); on a stream whose CU mask leaves a few CUs
+// per XCD out, those CUs are always free for the chain.  mm_debug_cu_probe reports where workgroups of a stream really ran.
+namespace {
+__global__ void cu_probe_kernel(unsigned* out, long long spin) {
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));       // HW_REG_XCC_ID
+    out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_REG_HW_ID: cu 11:8, sh 12, se 15:13
+  }
+}
+}  // namespace
+
+extern "C" int mm_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream) {
+  if (!mask || nwords <= 0 || !stream) return MM_ERR_ARG;
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask) != hipSuccess) { (void)hipGetLastError(); return MM_ERR_UNSUPPORTED; }
+  *stream = (void*)s;
+  return MM_OK;
+}
+extern "C" int mm_stream_destroy(void* stream) {
+  if (!stream) return MM_ERR_ARG;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? MM_OK : MM_ERR_ARG;
+}
+extern "C" int mm_device_cu_count(void) {
+  int d = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&p, d) != hipSuccess) return -1;
+  return p.multiProcessorCount;
+}
+// n_wg workgroups of `threads` threads, each holding its slot for `spin_ticks` of the 100 MHz counter; out[2 i] = XCC id register,
+// out[2 i + 1] = HW_ID register of workgroup i's first wave
+extern "C" int mm_debug_cu_probe(void* out_u32, int n_wg, int threads, int64_t spin_ticks, void* stream) {
+  if (!out_u32 || n_wg <= 0 || threads <= 0 || threads > 1024 || spin_ticks < 0 || spin_ticks > 100000000ll) return MM_ERR_ARG;
+  hipLaunchKernelGGL(cu_probe_kernel, dim3(n_wg), dim3(threads), 0, (hipStream_t)stream, (unsigned*)out_u32, spin_ticks);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}

@@ -674,3 +674,53 @@ def cast(src, dtype):
     dst = torch.empty(src.shape, dtype=dtype, device=src.device)
     call("mm_cast", dt(src), _DT[dtype], _p(src), _p(dst), src.numel(), _stream())
     return dst
+
+
+# ------------------------------------------------------------------------------------------------ CU-masked streams
+def cu_mask_words(n_enabled: int, ncu: int = 256, scheme: str = "hash"):
+    """Bit mask (list of uint32 words) with `n_enabled` of `ncu` CUs on.  The disabled CUs are spread so that every XCD and shader
+    engine loses about the same number whichever way the driver numbers CUs ("hash": the D smallest of (173 i) mod 256, a
+    permutation that is even both over i mod 8 and over i // 32; "stride": every (ncu / D)-th)."""
+    n_enabled = max(1, min(int(n_enabled), ncu))
+    D = ncu - n_enabled
+    if scheme == "stride":
+        off = {int((k + 0.5) * ncu / D) for k in range(D)} if D else set()
+    else:
+        off = set(sorted(range(ncu), key=lambda i: ((i * 173) % 256, i))[:D])
+    words = [0] * ((ncu + 31) // 32)
+    for i in range(ncu):
+        if i not in off:
+            words[i // 32] |= 1 << (i % 32)
+    return words
+
+
+_masked_streams = {}
+
+
+def masked_stream(n_enabled: int, scheme: str = "hash", tag: str = ""):
+    """A torch stream object over a HIP stream whose kernels run on `n_enabled` CUs only (cached per process; never destroyed: the
+    Trainer keeps them for its lifetime)."""
+    import ctypes
+    ncu = _lib.lib().mm_device_cu_count()
+    key = (torch.cuda.current_device(), int(n_enabled), scheme, tag)
+    st = _masked_streams.get(key)
+    if st is None:
+        words = cu_mask_words(n_enabled, ncu, scheme)
+        arr = (ctypes.c_uint32 * len(words))(*words)
+        out = ctypes.c_void_p()
+        call("mm_stream_create_cu_mask", ctypes.cast(arr, ctypes.c_void_p), len(words), ctypes.cast(ctypes.pointer(out), ctypes.c_void_p))
+        st = torch.cuda.ExternalStream(out.value)
+        _masked_streams[key] = st
+    return st
+
+
+def cu_probe(n_wg, threads, spin_ticks, stream=None):
+    """-> int64 [n_wg, 2] (XCC id, HW_ID register) of a spinning launch on `stream` (default: the current stream)."""
+    out = torch.zeros((n_wg, 2), dtype=torch.int32, device="cuda")
+    s = stream.cuda_stream if stream is not None else _stream()
+    if stream is not None:
+        stream.wait_stream(torch.cuda.current_stream())
+    call("mm_debug_cu_probe", _p(out), n_wg, threads, int(spin_ticks), s)
+    if stream is not None:
+        torch.cuda.current_stream().wait_stream(stream)
+    return out.cpu().long() & 0xFFFFFFFF

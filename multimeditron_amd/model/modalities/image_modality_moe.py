@@ -154,6 +154,10 @@ def _run_experts(experts, pixels, post=None):
     if frozen and pixels.is_cuda and os.environ.get("MM_MOE_GRAPH", "1") != "0":
         outs = _frozen_towers(experts, pixels, tower)
         return [post(e, o) if post is not None else o for e, o in enumerate(outs)]
+    if (not frozen and pixels.is_cuda and not pixels.requires_grad and os.environ.get("MM_MOE_GRAPH", "1") != "0"
+            and os.environ.get("MM_MOE_TRAIN_GRAPH", "1") != "0" and _graphable(experts)):
+        outs = _trainable_towers(experts, pixels, tower)
+        return [post(e, o) if post is not None else o for e, o in enumerate(outs)]
     if len(experts) == 1 or not pixels.is_cuda or os.environ.get("MM_MOE_STREAMS", "1") == "0":
         return [post(e, tower(e, ex)) if post is not None else tower(e, ex) for e, ex in enumerate(experts)]
     main = torch.cuda.current_stream()
@@ -209,6 +213,146 @@ def _frozen_towers(experts, pixels, tower):
     static_px.copy_(pixels)
     graph.replay()
     return [o.clone() for o in res]
+
+
+def _graphable(experts):
+    """Trainable towers can be replayed from captured graphs when every parameter's gradient lives in a flat buffer (the wgrad
+    kernels write `param.grad` in place: a gradient tensor allocated during capture would belong to the graph's pool)."""
+    return all(getattr(p, "_mm_flat", None) is not None for ex in experts for p in ex.parameters() if p.requires_grad)
+
+
+class _TowerGraphs:
+    """Forward and backward hipGraphs of E TRAINABLE expert towers for one pixel shape.  The forward graph is captured with
+    autograd recording, on E parallel branches; the autograd graph of that capture is kept, and the backward graphs are captured
+    by running it (per expert, on the expert's branch) -- one graph for `first gradient of the step` (the wgrad kernels overwrite)
+    and one for `accumulate`.  A replay costs the host two calls instead of ~1,200 launches per ViT-L/14 tower, which is what
+    bounds E trainable towers otherwise (E host-bound chains)."""
+
+    def __init__(self, experts, pixels, tower):
+        from ... import functional as F_
+        self.experts = experts
+        self.params = [p for ex in experts for p in ex.parameters() if p.requires_grad]
+        self.mods = [m for ex in experts for m in ex.modules() if m._forward_pre_hooks]
+        dev = pixels.device
+        self.streams = [_expert_stream(dev, e) for e in range(len(experts))]
+        self.static_px = pixels.detach().clone()
+        cur = torch.cuda.current_stream()
+        warm = torch.cuda.Stream()
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm), torch.no_grad():                      # lazy initialisation outside capture
+            for e, ex in enumerate(experts):
+                tower(e, ex, self.static_px)
+        cur.wait_stream(warm)
+        self.fwd = torch.cuda.CUDAGraph()
+        with torch.enable_grad(), torch.cuda.graph(self.fwd):
+            main = torch.cuda.current_stream()
+            self.res = []
+            for e, ex in enumerate(experts):
+                st = self.streams[e]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    self.res.append(tower(e, ex, self.static_px))
+            for st in self.streams:
+                main.wait_stream(st)
+        self.pool = self.fwd.pool()
+        self.static_g = [torch.zeros_like(o) for o in self.res]
+        self.bwd = {}
+        self.warmed = False
+        self._F = F_
+
+    def _flags(self, fresh):
+        for p in self.params:
+            p._mm_flat.ensure_grad()
+            p.grad = p._mm_grad_view
+            p._mm_fresh = fresh
+
+    def _run_autograd(self):
+        main = torch.cuda.current_stream()
+        for e, st in enumerate(self.streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                torch.autograd.backward([self.res[e]], [self.static_g[e]], retain_graph=True)
+        for st in self.streams:
+            main.wait_stream(st)
+
+    def forward(self, pixels):
+        for m in self.mods:                                                  # parameter-read hooks (the Trainer's per-block wait for
+            for hook in list(m._forward_pre_hooks.values()):                 # the overlapped optimiser): the replay calls no module
+                hook(m, ())
+        self.static_px.copy_(pixels)
+        self.fwd.replay()
+        return [o.detach().clone() for o in self.res]
+
+    def backward(self, grads):
+        F_ = self._F
+        p0 = self.params[0]
+        fresh = p0.grad is None or bool(getattr(p0, "_mm_fresh", False))
+        for sg, g in zip(self.static_g, grads):
+            if g is None:
+                sg.zero_()
+            else:
+                sg.copy_(g)
+        if not self.warmed:                 # first backward: eager, through the autograd graph of the capture (its saved tensors are
+            self.warmed = True              # the graph's buffers, which the forward replay has just filled) -- a real backward
+            self._flags(fresh)
+            hook, order = F_._grad_ready_hook, []
+
+            def spy(p):                     # which parameters report a finished gradient, and in which order: replays repeat it
+                order.append(p)
+                if hook is not None:
+                    hook(p)
+
+            F_.set_grad_ready_hook(spy)
+            try:
+                self._run_autograd()
+            finally:
+                F_.set_grad_ready_hook(hook)
+            self.ready_order = order
+            return
+        g = self.bwd.get(fresh)
+        if g is None:
+            hook = F_._grad_ready_hook
+            F_.set_grad_ready_hook(None)    # python side effects do not replay: the hooks are called after every replay instead
+            try:
+                self._flags(fresh)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool):
+                    self._run_autograd()
+            finally:
+                F_.set_grad_ready_hook(hook)
+            self.bwd[fresh] = g
+        self._flags(False)                  # what grad_target leaves behind: .grad attached, the next write accumulates
+        g.replay()
+        for p in self.ready_order:
+            F_._ready(p)
+
+
+class _TrainableTowersFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dummy, pixels, graphs):
+        ctx.graphs = graphs
+        return tuple(graphs.forward(pixels))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.graphs.backward(grads)
+        return None, None, None
+
+
+def _trainable_towers(experts, pixels, tower):
+    """Graph-replayed forward + backward of trainable expert towers (see _TowerGraphs); same kernels as the eager path."""
+    key = ("train", tuple(pixels.shape), pixels.dtype, experts[0].embeddings.position_embedding.weight.data_ptr(),
+           tuple(p.requires_grad for ex in experts for p in ex.parameters()))
+    cache = getattr(experts, "_mm_graphs", None)
+    if cache is None:
+        cache = experts._mm_graphs = {}
+    ent = cache.get(key)
+    if ent is None:
+        ent = cache[key] = _TowerGraphs(experts, pixels, tower)
+        if len(cache) > 8:
+            cache.pop(next(iter(cache)))
+    p0 = ent.params[0]
+    return list(_TrainableTowersFn.apply(grad_dummy(p0), pixels, ent))
 
 
 _EXPERT_STREAMS = {}

@@ -75,6 +75,9 @@ def scheduled_lr(kind: str, step: int, total: int, base_lr: float, min_lr: float
     raise ValueError(f"lr_scheduler_type {kind!r}: expected one of {LR_SCHEDULES}")
 
 
+_SIDE_CUS_DEFAULT = {"MM_ADAMW_CUS": 0, "MM_DEFER_CUS": 0}      # CUs a side burst may use (0 = all): see MultimodalTrainer._side_stream
+
+
 class MultimodalTrainer:
     def __init__(self, model, training_mode: TrainingMode = TrainingMode.ALIGNMENT, learning_rate: float = 1e-4,
                  weight_decay: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 1.0,
@@ -117,6 +120,16 @@ class MultimodalTrainer:
         self._setup_wgrad_deferral()
         self._setup_early_gradnorm()
 
+    def _side_stream(self, env: str, priority: int = 0):
+        """The HIP stream of a burst that runs beside a chain of small modality-tower kernels (AdamW beside the next ViT forward,
+        the deferred wgrad GEMMs beside the ViT backward).  `env` names the number of CUs the burst may use (kernels.masked_stream:
+        hipExtStreamCreateWithCUMask, the CUs left out spread evenly over the XCDs): the chain then always finds free CUs instead
+        of waiting for a CU to drain.  0 / unset = every CU (a plain stream)."""
+        n = int(os.environ.get(env, str(_SIDE_CUS_DEFAULT.get(env, 0))))
+        if n > 0 and torch.cuda.is_available():
+            return K.masked_stream(n, tag=env)
+        return torch.cuda.Stream(priority=priority)
+
     def _setup_wgrad_deferral(self):
         """Hold back the weight-gradient GEMMs of the first decoder layers (the last to run in backward) and launch them on a
         side stream beside the modality backward (functional.set_wgrad_deferral).  Only when a modality embedder is
@@ -155,7 +168,7 @@ class MultimodalTrainer:
             if head is not None and head.weight.requires_grad and head.weight is not self.model.model.get_input_embeddings().weight:
                 now.append(head.weight)
         prio = int(os.environ.get("MM_WGRAD_SIDE_PRIO", "0"))
-        self._wgrad_stream = torch.cuda.Stream(priority=prio)
+        self._wgrad_stream = self._side_stream("MM_DEFER_CUS", priority=prio)
         Fm.set_wgrad_deferral(self._wgrad_stream, ids, immediate=now)
 
     def _setup_early_gradnorm(self):
@@ -477,7 +490,7 @@ class MultimodalTrainer:
                 self._defer_from = len(self._blocks) - 1            # first decoder layer: see _launch_deferred
         covered = sum(b - a for _, rs in self._blocks for a, b, _, _ in rs)
         assert covered == sum(e - s0 for s0, e, _ in self.ranges), "optimizer pipeline must cover every trainable range"
-        self._opt_stream = torch.cuda.Stream()
+        self._opt_stream = self._side_stream("MM_ADAMW_CUS")
         self._pending: Dict[int, torch.cuda.Event] = {}
         self._all_done: Optional[torch.cuda.Event] = None
         self._hooks = []
@@ -505,7 +518,7 @@ class MultimodalTrainer:
             return (1 if llm else 0, 1 if (llm and decay) else 0, bk.start)
 
         self._bucket_order = sorted(range(len(ex.buckets)), key=order)
-        self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() and self.flat.device.type == "cuda" else None
+        self._opt_stream = self._side_stream("MM_ADAMW_CUS") if torch.cuda.is_available() and self.flat.device.type == "cuda" else None
 
         def block_key(name):
             m = re.match(r"(.*?layers\.\d+)\.", name)

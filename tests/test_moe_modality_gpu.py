@@ -199,3 +199,114 @@ def test_frozen_towers_graph_replay_equals_eager(moe, moe_pep, tmp_path, pep, mo
     trainable = [k for k, p in m.named_parameters() if p.requires_grad]
     assert trainable and all(dict(m.named_parameters())[k].grad is not None for k in trainable)
     assert all(p.grad is None for k, p in m.named_parameters() if k.startswith("experts."))
+
+
+@pytest.mark.parametrize("pep", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_trainable_towers_graph_replay_equals_eager(moe, moe_pep, tmp_path, pep, dtype, monkeypatch):
+    """TRAINABLE expert towers (the `full` recipe) replayed from captured forward / backward hipGraphs (_TowerGraphs) against the
+    eager launches: outputs and every gradient bit-identical (bf16; fp32: to 1e-6, its attention backward uses atomics), call after call -- the first backward (eager, through the capture's
+    autograd graph), the captured `first gradient of the step` graph, its replay, and the `accumulate` graph (no reset between
+    two backward passes); new pixels every call; the gradient-ready hook fires once per tower parameter per backward."""
+    from multimeditron_amd import functional as Fm
+    meta, w, v = moe_pep if pep else moe
+    px = v["pixels"]
+    g = torch.Generator().manual_seed(5)
+    batches = [[px[i] for i in range(px.shape[0])]] + [[torch.randn_like(px[0], generator=g) for _ in range(px.shape[0])] for _ in range(4)]
+    reset = [True, True, True, False, True]                                 # call 3 accumulates onto call 2's gradients
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MM_MOE_TRAIN_GRAPH", mode)
+        m = _build(meta, w, v, "cross_attn", dtype, tmp_path / f"g{mode}")
+        flat = next(iter(m.parameters()))._mm_flat
+        tower = [p for k, p in m.named_parameters() if k.startswith("experts.")]
+        fired = []
+        Fm.set_grad_ready_hook(lambda p: fired.append(id(p)))
+        try:
+            rec = []
+            for b, fresh in zip(batches, reset):
+                if fresh:
+                    flat.attach_grads(fresh=True)
+                fired.clear()
+                y = m(b)
+                (y.float() * torch.linspace(-1, 1, y.numel(), device=y.device).view_as(y)).sum().backward()
+                torch.cuda.synchronize()
+                assert sorted(i for i in fired if i in {id(p) for p in tower}) == sorted(id(p) for p in tower)
+                rec.append((y.detach().clone(), flat.grad.detach().clone()))
+        finally:
+            Fm.set_grad_ready_hook(None)
+        got[mode] = rec
+        if mode == "1":
+            ent = [e for k, e in m.experts._mm_graphs.items() if k[0] == "train"]
+            assert len(ent) == 1 and set(ent[0].bwd) == {True, False}      # both backward graphs were captured and replayed
+    for i, ((y0, g0), (y1, g1)) in enumerate(zip(got["0"], got["1"])):
+        assert torch.equal(y0, y1), i
+        if dtype == torch.bfloat16:
+            assert torch.equal(g0, g1), (i, float((g0.float() - g1.float()).abs().max()))
+        else:       # the fp32 parity kernels' attention backward sums dq with atomics: equal to rounding, not bit for bit, run to run
+            assert float((g0 - g1).norm()) <= 1e-6 * float(g0.norm()), (i, float((g0 - g1).abs().max()))
+    assert not torch.equal(got["1"][1][1], got["1"][2][1])
+
+
+def test_moe_full_recipe_trainer_steps_graph_equals_eager(tmp_path, monkeypatch):
+    """The MoE `full` recipe (trainable towers) under MultimodalTrainer, optimiser overlapped with the next forward: three
+    steps with the towers replayed from graphs against three steps of eager launches from the same weights -- same losses, same
+    parameters bit for bit (bf16).  Covers what a replay must do by hand: the Trainer's per-block parameter-read hooks before the
+    forward replay, the gradient-ready hook after the backward replay, `.grad` / overwrite-vs-accumulate state."""
+    import bench
+    from tests.test_training_config_cpu import ATTACH, make_tokenizer
+    from multimeditron_amd.train import from_training_config
+    llm = os.path.join(str(tmp_path), "llm")                 # head width 64 everywhere: what the bf16 attention kernels hold
+    os.makedirs(llm, exist_ok=True)
+    json.dump(dict(model_type="llama", hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                   num_key_value_heads=1, head_dim=64, vocab_size=32, rms_norm_eps=1e-5, tie_word_embeddings=False,
+                   rope_parameters={"rope_type": "default", "rope_theta": 10000.0}), open(os.path.join(llm, "config.json"), "w"))
+    clips = []
+    for i in range(3):
+        d = os.path.join(str(tmp_path), f"clip{i}")
+        os.makedirs(d, exist_ok=True)
+        json.dump({"vision_config": dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=32,
+                                         patch_size=16)}, open(os.path.join(d, "config.json"), "w"))
+        json.dump({"size": {"shortest_edge": 32}, "crop_size": {"height": 32, "width": 32}}, open(os.path.join(d, "preprocessor_config.json"), "w"))
+        clips.append(d)
+    recipe = {
+        "base_llm": llm, "base_model": None, "attachment_token": ATTACH, "tokenizer_type": "llama", "token_size": 128,
+        "loaders": [{"loader_type": "raw-image", "modality_type": "image"}],
+        "modalities": [{"model_type": "moe_meditron_clip_shared", "image_processor": clips[0], "hidden_size": 128, "expert_clip_names": clips,
+                        "generalist_idx": -1, "gating_path": "stub", "fusion_method": "cross_attn", "top_k_experts": 3, "cross_attn_heads": 2}],
+        "training_mode": "FULL",
+        "training_args": {"learning_rate": 1.0e-3, "bf16": True, "per_device_train_batch_size": 2, "gradient_accumulation_steps": 2,
+                          "max_steps": 50, "max_grad_norm": 1.0, "lr_scheduler_type": "constant", "weight_decay": 0.01},
+    }
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MM_MOE_TRAIN_GRAPH", mode)
+        torch.manual_seed(0)
+        setup = from_training_config(recipe, make_tokenizer(), device="cuda", dtype="bfloat16")
+        model, tr = setup.model, setup.trainer
+
+        def gate(px):                    # test-side stand-in for the reference's ResNet gate (a plug: DESIGN.md section 7)
+            logits = px.float().mean(dim=(2, 3)) @ torch.tensor([[1.0, 0.5, -0.5], [0.2, -0.3, 0.7], [-0.4, 0.9, 0.1]], device=px.device)
+            return logits, logits.topk(1, dim=-1).indices, torch.softmax(logits, dim=-1)
+
+        model.modalities_by_type["image"].gating_network = gate
+        model.eval()                     # no dropout: the two runs must agree bit for bit
+        model.train = lambda *_a, **_k: model
+        vocab = model.config.vocab_size
+        losses = []
+        for step in range(6):            # 6 micro-batches = 3 optimiser steps (the second micro-batch of a step accumulates)
+            batch, _ = bench.synthetic_batch(2, 24, 1, 4, vocab, (vocab - 3, vocab - 2, vocab - 1), 100 + step, "cpu", 32, collator_form=True)
+            batch["input_ids"].clamp_(max=vocab - 1)
+            batch["labels"] = torch.where(batch["labels"] >= 0, batch["labels"].clamp(max=vocab - 1), batch["labels"])
+            losses.append(float(tr.training_step(batch)))
+        tr.synchronize()
+        torch.cuda.synchronize()
+        mod = model.modalities_by_type["image"]
+        if mode == "1":
+            ent = [e for k, e in mod.experts._mm_graphs.items() if k[0] == "train"]
+            assert len(ent) == 1 and set(ent[0].bwd) == {True, False}
+        res[mode] = (losses, tr.flat.data.detach().clone())
+        tr.close()
+    assert res["0"][0] == res["1"][0], (res["0"][0], res["1"][0])
+    assert torch.equal(res["0"][1], res["1"][1])
+    assert all(l == l for l in res["0"][0])

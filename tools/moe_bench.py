@@ -26,19 +26,20 @@ for fusion in ("weighted_average", "cross_attn"):
         p.requires_grad_(True)
     px = torch.randn(n, 3, 224, 224, device="cuda")
     ref = None
-    for streams in ("0", "1", "0", "1"):
+    for streams, graph in (("0", "0"), ("1", "0"), ("1", "1"), ("0", "0"), ("1", "0"), ("1", "1")):
         os.environ["MM_MOE_STREAMS"] = streams
-        for it in range(3):
-            if it == 1:
+        os.environ["MM_MOE_TRAIN_GRAPH"] = graph        # trainable towers replayed from captured forward / backward graphs
+        for it in range(6):
+            if it == 3:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             y = m(px)
             y.backward(torch.ones_like(y))
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 2 * 1e3
+        ms = (time.perf_counter() - t0) / 3 * 1e3
         same = "" if ref is None else f"  output identical to the sequential run: {bool(torch.equal(ref, y))}"
         ref = y.detach().clone() if ref is None else ref
-        print(f"{fusion}: E={E} experts (ViT-L/14), n={n} images, MM_MOE_STREAMS={streams}: {ms:.2f} ms fwd+bwd{same}", flush=True)
+        print(f"{fusion}: E={E} experts (ViT-L/14), n={n} images, MM_MOE_STREAMS={streams} MM_MOE_TRAIN_GRAPH={graph}: {ms:.2f} ms fwd+bwd{same}", flush=True)
     # the shipped alignment / end2end recipes: towers frozen, projector (and cross-attention) trainable
     m.freeze_modality_embedder()
     for graph in ("0", "1", "0", "1"):

@@ -11,4 +11,4 @@ csv=$(find $O/kt -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/stream_time.py $csv > $O/stream_time.txt 2>&1
 python3 $R/tools/gap_analysis.py $csv 30 > $O/gaps.txt 2>&1
 rm -rf $O/kt
-head -60 $O/stream_time.txt
+tail -70 $O/stream_time.txt | cut -c1-200

@@ -8,7 +8,7 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 qk = "Stream_Id" if "Stream_Id" in rows[0] else "Queue_Id"
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r[qk], r.get("Grid_Size_X", r.get("Grid_Size", "?"))) for r in rows))
-ad = [s for s, e, n, q, g in ev if "adamw_kernel" in n]
+ad = [s for s, e, n, q, g in ev if "adamw_" in n]
 bounds = [ad[0]] + [ad[i] for i in range(1, len(ad)) if ad[i] - ad[i - 1] > 100e6]
 a, b = bounds[-2], bounds[-1]
 win = [x for x in ev if a <= x[0] < b]
@@ -26,3 +26,25 @@ for q, xs in sorted(by_q.items(), key=lambda kv: -sum(e - s for s, e, *_ in kv[1
         agg[k][1] += e - s
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
         print(f"   {k:72s} {c:5d}  {t / 1e6:8.2f} ms  avg {t / c / 1e3:8.1f} us")
+
+# ---- what the compute stream does while each side stream is busy (the overlap windows of DESIGN.md section 6)
+main_q = max(by_q, key=lambda q: sum(e - s for s, e, *_ in by_q[q]))
+for q, xs in by_q.items():
+    if q == main_q:
+        continue
+    w0, w1 = min(s for s, *_ in xs), max(e for _, e, *_ in xs)
+    inside = [x for x in by_q[main_q] if x[1] > w0 and x[0] < w1]
+    busy = sum(min(e, w1) - max(s, w0) for s, e, *_ in inside)
+    print(f"\n== window of stream {q}: {(w0 - a) / 1e6:.2f} .. {(w1 - a) / 1e6:.2f} ms of the step ({(w1 - w0) / 1e6:.2f} ms); side busy "
+          f"{sum(e - s for s, e, *_ in xs) / 1e6:.2f} ms; compute stream inside it: {len(inside)} launches, busy {busy / 1e6:.2f} ms, idle {(w1 - w0 - busy) / 1e6:.2f} ms")
+    agg = collections.defaultdict(lambda: [0, 0])
+    for s, e, n, _, g in inside:
+        k = (n[n.find("::") + 2:] if n.startswith("void (anonymous") or n.startswith("(anonymous") else n)[:58] + f" g={g}"
+        agg[k][0] += 1
+        agg[k][1] += min(e, w1) - max(s, w0)
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"   {k:72s} {c:5d}  {t / 1e6:8.2f} ms  avg {t / c / 1e3:8.1f} us")
+    after = [x for x in by_q[main_q] if x[0] >= w1][:3]
+    before = [x for x in by_q[main_q] if x[1] <= w0][-2:]
+    print("   compute stream just before:", [(n[:40], round((e - s) / 1e3, 1)) for s, e, n, *_ in before])
+    print("   compute stream just after: ", [(n[:40], round((s - w1) / 1e3, 1), round((e - s) / 1e3, 1)) for s, e, n, *_ in after])
