@@ -202,21 +202,21 @@ int mm_rope_append(int dtype, void* x, int T, int Hq, int Hkv, int D, int ld, co
                    void* kdst, void* vdst, int64_t dstride, void* stream);
 
 /* ---- decode-step fusions on the weight-streaming GEMM (KV-cache decode of `generate`, reference model.py:595-602; M = batch <= 16;
- * MM_BF16).  Each replaces a GEMM + one tiny launch of HF's LlamaDecoderLayer (HF:llama:284-325) with the arithmetic and rounding
- * points of the separate kernels (same bits):
- * mm_decode_gateup_swiglu:   ACT[M,I] = silu(x Wg^T) * (x Wu^T), Wgu = fused [2I,K] gate|up weight      (= mm_gemm + mm_swiglu_fwd)
- * mm_decode_qkv_rope_append: QKV[M,(Hq+2Hkv)*128] = x W^T (+ bias), q and k heads rotated with cos_t / sin_t [M,64], roped k and v
- *                            appended to the KV cache rows kdst / vdst (+ m * dstride)                  (= mm_gemm + mm_rope_append)
- * mm_decode_linear_norm:     C[M,N] = x W^T + residual AND Y[M,N] = RMSNorm(C) * norm_w for the next projection, the norm done by
- *                            the workgroup that finishes last (counter: one zero-initialised uint32 the kernel leaves at zero)
- *                                                                                                       (= mm_gemm + mm_rmsnorm_fwd) */
+ * MM_BF16).  Each replaces a GEMM + the tiny launches around it in HF's LlamaDecoderLayer (HF:llama:284-325) with the arithmetic
+ * and rounding points of the separate kernels (same bits).  `in_norm_w` (may be NULL) / `eps`: the RMSNorm IN FRONT of the projection
+ * (input_layernorm, post_attention_layernorm, the model's final norm), applied to x while it is staged: y = x' W^T with
+ * x' = RMSNorm(x) * in_norm_w.  M * K * 2 bytes of x must fit 144 KB of LDS (MM_ERR_UNSUPPORTED otherwise: use the separate kernels).
+ * mm_decode_gateup_swiglu:   ACT[M,I] = silu(x' Wg^T) * (x' Wu^T), Wgu = fused [2I,K] gate|up weight    (= [mm_rmsnorm_fwd +] mm_gemm + mm_swiglu_fwd)
+ * mm_decode_qkv_rope_append: QKV[M,(Hq+2Hkv)*128] = x' W^T (+ bias), q and k heads rotated with cos_t / sin_t [M,64], roped k and v
+ *                            appended to the KV cache rows kdst / vdst (+ m * dstride)                  (= [mm_rmsnorm_fwd +] mm_gemm + mm_rope_append)
+ * mm_decode_linear:          C[M,N] = x' W^T (+ bias) (+ residual)                                      (= [mm_rmsnorm_fwd +] mm_gemm)             */
 int mm_decode_gateup_swiglu(int dtype, int M, int I, int K, const void* X, int ldx, const void* Wgu, int ldw, void* ACT, int ldact,
-                            void* stream);
+                            const void* in_norm_w, float eps, void* stream);
 int mm_decode_qkv_rope_append(int dtype, int M, int Hq, int Hkv, int D, int K, const void* X, int ldx, const void* W, int ldw,
                               const void* bias, void* QKV, int ldqkv, const float* cos_t, const float* sin_t, void* kdst, void* vdst,
-                              int64_t dstride, void* stream);
-int mm_decode_linear_norm(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* residual, int ldr,
-                          void* C, int ldc, const void* norm_w, float eps, void* Y, int ldy, void* counter, void* stream);
+                              int64_t dstride, const void* in_norm_w, float eps, void* stream);
+int mm_decode_linear(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* bias,
+                     const void* residual, int ldr, void* C, int ldc, const void* in_norm_w, float eps, void* stream);
 
 /* KV-cache decode step: ONE query token per sequence over the cached keys (reference model.py:595-602 calling the LLM with
  * past_key_values; HF:llama:217-281 with q_len = 1).  q [B,Hq,D] (strides q_sb,q_sh; D contiguous), k/v [B,Skv,Hkv,D] as

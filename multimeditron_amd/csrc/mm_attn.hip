@@ -2289,7 +2289,8 @@ template <int D, int G>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(DecodeArgs a) {
   constexpr int LPK = D / 8;            // lanes per key row
   constexpr int KPI = 64 / LPK;         // keys per wave-instruction
-  constexpr int U = 4;                  // key rows in flight per lane (x2: K and V)
+  constexpr int U = 4;                  // key rows in flight per lane (x2: K and V).  8 (a whole 86-key slice of the 8B decoder at
+                                        // S = 2048 in ONE batch of loads) measured the same 17 us per launch: not what bounds it
   __shared__ float red[4][G][D + 2];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int sub = l % LPK, grp = l / LPK;

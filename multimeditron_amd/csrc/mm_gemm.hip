@@ -1160,14 +1160,13 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------------
 // Decode-step fusions on the weight-streaming kernel (round 3).  A decode step of the 8B decoder was ~320 launches of which
 // ~190 were tiny (RMSNorm of 4 rows, SwiGLU, RoPE + cache append, the split merge): 4.5-6 us each on the timeline for a few
-// KB of work.  Three of them become epilogues of the GEMM that produces their input (same arithmetic, same rounding points):
+// KB of work.  They become prologues / epilogues of the GEMM that consumes / produces their data (same arithmetic, same
+// rounding points):
+//   NORM    the RMSNorm in FRONT of a projection, applied while the workgroup stages x into LDS
 //   MODE 1  gate|up + SwiGLU     a workgroup streams 8 gate rows and the 8 matching up rows of the fused [2I, K] weight; after the
 //                                K-split sums meet in LDS a lane has g and u of a feature: act = bf16(bf16(silu(g)) * u)
 //   MODE 2  q|k|v + RoPE + KV-cache append   8 rows d .. d+7 and their rotate_half partners d+64 .. of one 128-wide head; the
 //                                epilogue rotates q / k heads (rope_lo / rope_hi), writes q|k|v and appends k, v to the cache row
-//   norm tail (MODE 0)           C = x W^T + residual, then y = RMSNorm(C) * w for the NEXT projection, computed by the workgroup
-//                                that finishes last (arrival counter; write-through stores + one agent-scope acquire by the last
-//                                arriver: cdna_hip_programming.md Guideline 16) with rmsnorm_fwd_kernel's own row routine (same bits)
 // ------------------------------------------------------------------------------------------------------
 struct SkinnyArgs {
   int M, N, K;
@@ -1180,131 +1179,209 @@ struct SkinnyArgs {
   int Hq, Hkv;                                  // MODE 2
   const float* cos_t; const float* sin_t;       // [M, 64]
   bf16* kdst; bf16* vdst; int64_t dstride;      // cache row of this step for sequence 0; elements between sequences
-  const bf16* norm_w; float eps; bf16* Y; int ldy; unsigned* counter;      // norm tail (norm_w == nullptr: none)
+  const bf16* norm_w; float eps;                // NORM: weight / eps of the RMSNorm in front of the projection (nullptr: none)
+  int epi;                                      // gemv_stream_kernel MODE 0: MM_EPI_* activation / accumulate flags
 };
 
-// RMSNorm of R rows by 256 threads: EXACTLY rmsnorm_fwd_kernel's arithmetic and summation order (mm_rowwise.hip), so the fused
-// tail gives the bits of the separate launch.  x is read with sc1 loads (written by other workgroups of this launch); the loads
-// of all R rows are issued before the first reduction (one memory round trip for the tail, not one per row).
+// ------------------------------------------------------------------------------------------------------
+// gemv_stream_kernel: the weight-streaming kernel of the decode step, second form (round 3).  Same work split as
+// gemm_skinny_kernel (one workgroup = 16 rows of W, its 8 waves split K, the 8 partial tiles summed through LDS in wave order:
+// the same bits), but laid out for BYTES IN FLIGHT:
+//   * a wave keeps a ring of U = 16 W loads (16 KiB) in flight and refills a slot right after the MFMA that consumed it; the
+//     older form issued 8, waited for all 8, multiplied, issued 8 more: an empty memory queue once per batch (K = 4096 is two
+//     batches per wave, so half of every such launch was spent with nothing requested);
+//   * x (M <= 16 rows, the MFMA's other operand) is staged ONCE per workgroup into LDS instead of being re-read from L2 at every
+//     K-step into registers: the vector-memory queue and the registers belong to W alone;
+//   * NORM: the RMSNorm in front of the projection (HF:llama LlamaRMSNorm) is applied while x is staged -- every workgroup
+//     normalises the M rows itself (M x K elements: nothing beside 16 x K of weights), with rmsnorm_fwd_kernel's own arithmetic
+//     and summation order, so the bits are those of the separate launch.  A decode layer is then 6 launches with NO norm
+//     launches and no cross-workgroup hand-off (the round's first form ran the NEXT norm in the GEMM's last-arriving workgroup:
+//     a device-scope ticket plus a dependent round trip, ~6 us per launch, twice per layer).
+// MODE 0 plain epilogue (bias, activation, residual, accumulate; any N), 1 gate|up + SwiGLU, 2 q|k|v + RoPE + KV-cache append.
+// NT: non-temporal policy on the W loads (read once).
+// ------------------------------------------------------------------------------------------------------
 template <int CH, int R>
-__device__ __forceinline__ void rmsnorm_rows_256(const bf16* x, int ldx, const bf16* w, int H, float eps, bf16* y, int ldy, int nrows, float* red) {
+__device__ __forceinline__ void rmsnorm_rows_to_lds(const bf16* x, int ldx, const bf16* w, int H, float eps, char* xs, int nrows, float* red) {
+  // rmsnorm_fwd_kernel's arithmetic (mm_rowwise.hip) for rows 0 .. nrows-1, R rows' loads in flight at a time; threads >= 256 idle
   const int t = threadIdx.x;
-  bf16x8 xv[R][CH];
+  for (int r0 = 0; r0 < nrows; r0 += R) {
+    bf16x8 xv[R][CH];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    auto rx = make_rsrc(x + (int64_t)r * ldx, r < nrows ? (int64_t)H * 2 : 0);
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int e = (c * 256 + t) * 8;
-      xv[r][c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, (t < 256 && e < H) ? (unsigned)e * 2u : 0xFFFFFFFFu, 0, 16));
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (r < nrows) {                                     // uniform
-      float ss = 0.f;
+    for (int r = 0; r < R; ++r) {
+      auto rx = make_rsrc(x + (int64_t)(r0 + r) * ldx, (r0 + r) < nrows ? (int64_t)H * 2 : 0);
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const int e = (c * 256 + t) * 8;
-        if (t < 256 && e < H) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { const float f = (float)xv[r][c][i]; ss += f * f; }
-        }
+        xv[r][c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, (t < 256 && e < H) ? (unsigned)e * 2u : 0xFFFFFFFFu, 0, 0));
       }
-      ss = block_sum_256(ss, red);
-      const float rs = rsqrtf(ss / (float)H + eps);
+    }
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int e = (c * 256 + t) * 8;
-        if (t < 256 && e < H) {
-          const bf16x8 wv = *(const bf16x8*)(w + e);
-          bf16x8 o;
+    for (int r = 0; r < R; ++r) {
+      if (r0 + r < nrows) {                                // uniform
+        float ss = 0.f;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float nrm = (float)(bf16)((float)xv[r][c][i] * rs);
-            o[i] = (bf16)((float)wv[i] * nrm);
+        for (int c = 0; c < CH; ++c) {
+          const int e = (c * 256 + t) * 8;
+          if (t < 256 && e < H) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float f = (float)xv[r][c][i]; ss += f * f; }
           }
-          *(bf16x8*)(y + (int64_t)r * ldy + e) = o;
+        }
+        ss = block_sum_256(ss, red);
+        const float rs = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int e = (c * 256 + t) * 8;
+          if (t < 256 && e < H) {
+            const bf16x8 wv = *(const bf16x8*)(w + e);
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float nrm = (float)(bf16)((float)xv[r][c][i] * rs);
+              o[i] = (bf16)((float)wv[i] * nrm);
+            }
+            *(bf16x8*)(xs + ((int64_t)(r0 + r) * H + e) * 2) = o;
+          }
         }
       }
     }
   }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(512) void gemm_skinny_fused_kernel(SkinnyArgs g) {
-  __shared__ float red[8][4][64];
+template <int MODE, bool NORM, bool NT>
+__global__ __launch_bounds__(512, 4) void gemv_stream_kernel(SkinnyArgs g, int nblocks) {      // 4 waves per SIMD (2 workgroups per CU): <= 128 VGPRs
+  extern __shared__ __attribute__((aligned(16))) char xs[];          // x, M rows of K bf16 (normalised when NORM)
+  __shared__ float red[2][8][4][64];
   __shared__ float nred[8];
-  __shared__ int s_last;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = l & 15, kc = l >> 4;
-  int wr;                                                   // the lane's row of W (as MFMA A-operand row `row`), -1 = none
-  if constexpr (MODE == 1) {
-    const int f = blockIdx.x * 8 + (row & 7);
-    wr = f < g.I ? f + (row >> 3) * g.I : -1;
-  } else if constexpr (MODE == 2) {
-    wr = (blockIdx.x >> 3) * 128 + (blockIdx.x & 7) * 8 + (row & 7) + (row >> 3) * 64;
-  } else {
-    wr = blockIdx.x * 16 + row;
-    if (wr >= g.N) wr = -1;
-  }
-  auto rw = make_rsrc(g.B, (int64_t)(MODE == 1 ? 2 * g.I : g.N) * g.ldb * 2);
-  auto rx = make_rsrc(g.A, (int64_t)g.M * g.lda * 2);
-  const int nks = (g.K + 31) / 32;
-  const int per = (nks + 7) / 8;
-  const int ks0 = w * per, ks1 = min(nks, ks0 + per);
-  const unsigned wrow = wr < 0 ? 0xFFFFFFFFu : (unsigned)wr * (unsigned)g.ldb * 2u, xrow = (unsigned)(row * g.lda) * 2u;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 8;
-  for (int ks = ks0; ks < ks1; ks += U) {
-    u32x4 fw[U], fx[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = (ks + u) * 32 + kc * 8;
-      const bool ok = (ks + u) < ks1 && k < g.K;
-      fw[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, (ok && wr >= 0) ? wrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, 0);
-      fx[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, 0);
+  // the lane's row of W in row block `blk` (as MFMA A-operand row `row`) as a byte offset, or out of range
+  auto wrow_of = [&](int blk) -> unsigned {
+    int wr;
+    if (blk >= nblocks) return 0xFFFFFFFFu;
+    if constexpr (MODE == 1) {
+      const int f = blk * 8 + (row & 7);
+      wr = f < g.I ? f + (row >> 3) * g.I : -1;
+    } else if constexpr (MODE == 2) {
+      wr = (blk >> 3) * 128 + (blk & 7) * 8 + (row & 7) + (row >> 3) * 64;
+    } else {
+      wr = blk * 16 + row;
+      if (wr >= g.N) wr = -1;
     }
+    return wr < 0 ? 0xFFFFFFFFu : (unsigned)wr * (unsigned)g.ldb * 2u;
+  };
+  auto rw = make_rsrc(g.B, (int64_t)(MODE == 1 ? 2 * g.I : g.N) * g.ldb * 2);
+  constexpr int U = 16;
+  constexpr int WPOL = NT ? 2 : 0;
+  const int nks = (g.K + 31) / 32;
+  const int per = (nks + 7) / 8;                            // K-steps per wave and row block (the wave's share of K) ...
+  const int ipb = (per + U - 1) / U;                        // ... walked in ipb rounds of the U-slot ring (steps beyond `per` load nothing)
+  const int ks0 = w * per, ks1 = min(nks, ks0 + per);
+  u32x4 fw[U];
+  // PERSISTENT: the workgroup walks row blocks blockIdx.x, + gridDim.x, ...; x is staged (and normalised) once, the ring runs across
+  // block boundaries (the slot a step frees is refilled with the same step of the NEXT block when this block has no further round)
+  auto issue = [&](int u, unsigned wrow, int i) {            // i = step inside the block
+    const int ks = ks0 + i;
+    const int k = ks * 32 + kc * 8;
+    const bool ok = i < per && ks < ks1 && k < g.K && wrow != 0xFFFFFFFFu;
+    fw[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? wrow + (unsigned)k * 2u : 0xFFFFFFFFu, 0, WPOL);
+  };
+  int blk = blockIdx.x;
+  unsigned wrow = wrow_of(blk);
+  // ---- x -> LDS.  Plain: requested first (L2 hits), stored once the W ring has been requested behind it.  NORM: the rows pass
+  // through registers (sum of squares); half of the ring is requested before, the other half after (the norm's own registers and
+  // the whole ring together would not leave room for two workgroups per CU).
+  const int xchunks = g.M * (g.K / 8);                      // 16-byte chunks of x (K % 8 == 0: host)
+  if constexpr (NORM) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[u]), __builtin_bit_cast(bf16x8, fx[u]), acc, 0, 0, 0);
-  }
+    for (int u = 0; u < U / 2; ++u) issue(u, wrow, u);
+    if (g.K <= 2048) rmsnorm_rows_to_lds<1, 4>(g.A, g.lda, g.norm_w, g.K, g.eps, xs, g.M, nred);
+    else if (g.K <= 4096) rmsnorm_rows_to_lds<2, 4>(g.A, g.lda, g.norm_w, g.K, g.eps, xs, g.M, nred);
+    else rmsnorm_rows_to_lds<4, 2>(g.A, g.lda, g.norm_w, g.K, g.eps, xs, g.M, nred);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[w][r][l] = acc[r];
-  __syncthreads();
-  // wave 0, lane: m = l & 15, local W rows 4 * (l >> 4) + r
-  const int m = l & 15, gq = l >> 4;
-  if (w == 0 && m < g.M) {
-    if constexpr (MODE == 0) {
-      const int n = blockIdx.x * 16 + 4 * gq;
-      if (n < g.N) {                                         // N % 4 == 0 (host)
-        bf16x4 o;
+    for (int u = U / 2; u < U; ++u) issue(u, wrow, u);
+  } else {
+    constexpr int XU = 8;                                   // chunks per thread and pass
+    const int cpr = g.K / 8;
+    bool first = true;
+    for (int base = 0; base < xchunks; base += 512 * XU) {
+      u32x4 xv[XU];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t = 0.f;
-#pragma unroll
-          for (int ww = 0; ww < 8; ++ww) t += red[ww][r][l];
-          if (g.bias) t += (float)g.bias[n + r];
-          if (g.residual) t += (float)g.residual[(int64_t)m * g.ldr + n + r];
-          o[r] = (bf16)t;
-        }
-        auto rc = make_rsrc(g.C + (int64_t)m * g.ldc, (int64_t)g.N * 2);
-        // sc1 (write-through) when another workgroup will read C inside this launch (the norm tail)
-        if (g.norm_w) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rc, (unsigned)n * 2u, 0, 16);
-        else *(bf16x4*)(g.C + (int64_t)m * g.ldc + n) = o;
+      for (int j = 0; j < XU; ++j) {
+        const int i = base + j * 512 + (int)threadIdx.x;
+        const int r = i / cpr, c = i - r * cpr;
+        xv[j] = i < xchunks ? *(const u32x4*)(g.A + (int64_t)r * g.lda + c * 8) : u32x4{0u, 0u, 0u, 0u};
       }
-    } else if (gq < 2) {                                     // MODE 1 / 2: lanes 0-31 own the pairs (own rows, lane + 32's rows)
-      float v1[4], v2[4];
+      if (first) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) issue(u, wrow, u);
+        first = false;
+      }
+#pragma unroll
+      for (int j = 0; j < XU; ++j) {
+        const int i = base + j * 512 + (int)threadIdx.x;
+        if (i < xchunks) *(u32x4*)(xs + (int64_t)i * 16) = xv[j];
+      }
+    }
+  }
+  __syncthreads();
+  const char* xrow = xs + (int64_t)row * g.K * 2 + kc * 16;
+  const bool xlane = row < g.M;
+  const int m = l & 15, gq = l >> 4;                        // epilogue (wave 0): m = activation row, local W rows 4 * gq + r
+  for (int j = 0; blk < nblocks; ++j, blk += gridDim.x) {
+    const unsigned wnext = wrow_of(blk + gridDim.x);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < ipb; ++it) {
+      const bool more = it + 1 < ipb;                       // another round of this block, or on to the next block
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = it * U + u, kk = ks0 + i;
+        u32x4 fx = {0u, 0u, 0u, 0u};
+        if (xlane && i < per && kk < ks1 && kk * 32 + kc * 8 < g.K) fx = *(const u32x4*)(xrow + kk * 64);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[u]), __builtin_bit_cast(bf16x8, fx), acc, 0, 0, 0);
+        issue(u, more ? wrow : wnext, more ? i + U : u);
+      }
+    }
+    wrow = wnext;
+    float (*rb)[4][64] = red[j & 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb[w][r][l] = acc[r];
+    __syncthreads();                 // red[j & 1] is rewritten two blocks later: wave 0 has passed the barrier in between
+    if (w != 0) continue;
+    if constexpr (MODE == 0) {
+      if (m >= g.M) continue;
+      const int n = blk * 16 + 4 * gq;
+      if (n >= g.N) continue;
+      const int epi = g.epi;
+      bf16* cp = g.C + (int64_t)m * g.ldc + n;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float a = 0.f, b = 0.f;
+        if (n + r >= g.N) break;
+        float t = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 8; ++ww) { a += red[ww][r][l]; b += red[ww][r][l + 32]; }
-        v1[r] = a;
-        v2[r] = b;
+        for (int ww = 0; ww < 8; ++ww) t += rb[ww][r][l];
+        if (g.bias) t += (float)g.bias[n + r];
+        if (epi & MM_EPI_GELU_ERF) t = act_gelu_erf(t);
+        else if (epi & MM_EPI_QUICK_GELU) t = act_quick_gelu(t);
+        else if (epi & MM_EPI_GELU_TANH) t = act_gelu_tanh(t);
+        if (g.residual) t += (float)g.residual[(int64_t)m * g.ldr + n + r];
+        if (epi & MM_EPI_ACCUMULATE) t += (float)cp[r];
+        cp[r] = (bf16)t;
       }
+    } else {                                                 // MODE 1 / 2: lanes 0-31 own the pairs (own rows, lane + 32's rows)
+      float v1[4], v2[4];                                    // every lane sums its own rows (wave order), then takes lane + 32's sums
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) a += rb[ww][r][l];
+        v1[r] = a;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v2[r] = __shfl(v1[r], (l + 32) & 63, 64);
+      if (gq >= 2 || m >= g.M) continue;
       if constexpr (MODE == 1) {
-        const int f = blockIdx.x * 8 + 4 * gq;
+        const int f = blk * 8 + 4 * gq;
         if (f < g.I) {                                       // I % 4 == 0 (host)
           bf16x4 o;
 #pragma unroll
@@ -1316,7 +1393,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_fused_kernel(SkinnyArgs g) {
           *(bf16x4*)(g.C + (int64_t)m * g.ldc + f) = o;
         }
       } else {
-        const int h = blockIdx.x >> 3, d = (blockIdx.x & 7) * 8 + 4 * gq;
+        const int h = blk >> 3, d = (blk & 7) * 8 + 4 * gq;
         bf16x4 o1, o2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1343,35 +1420,6 @@ __global__ __launch_bounds__(512) void gemm_skinny_fused_kernel(SkinnyArgs g) {
           *(bf16x4*)(dp + 64) = o2;
         }
       }
-    }
-  }
-  if constexpr (MODE == 0) {
-    if (!g.norm_w) return;
-    // ---- norm tail: the workgroup that arrives last normalises the M rows of C
-    // Hand-off (cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md "Valid forms"): every byte of C is stored sc1
-    // (write-through) by wave 0, which drains its stores before its lane 0 takes the ticket -- no agent-scope RELEASE (a
-    // `buffer_wbl2` per workgroup cost ~10 us per launch here: the L2 is full of dirty KV-cache and activation lines); the last
-    // arriver makes ONE agent-scope ACQUIRE and reads C with sc1 loads.
-    if (threadIdx.x == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this workgroup's C stores (wave 0's, sc1) have left
-      const unsigned old = __hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (old + 1u) == gridDim.x;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(g.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch (same stream: ordered)
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    for (int r = 0; r < g.M; r += 4) {                   // four rows' loads in flight at a time
-      const bf16* xr = g.C + (int64_t)r * g.ldc;
-      bf16* yr = g.Y + (int64_t)r * g.ldy;
-      const int nr = min(4, g.M - r);
-      if (g.N <= 2048) rmsnorm_rows_256<1, 4>(xr, g.ldc, g.norm_w, g.N, g.eps, yr, g.ldy, nr, nred);
-      else if (g.N <= 4096) rmsnorm_rows_256<2, 4>(xr, g.ldc, g.norm_w, g.N, g.eps, yr, g.ldy, nr, nred);
-      else rmsnorm_rows_256<4, 4>(xr, g.ldc, g.norm_w, g.N, g.eps, yr, g.ldy, nr, nred);
     }
   }
 }
@@ -1508,6 +1556,9 @@ static int g_opt_persist = 1;   // walk tiles with resident workgroups
 static int g_opt_kernel = 0;    // 0 auto, 1 v1 (128x128 register staged), 2..6 LDS-DMA tiles 256x128, 256x256, 128x128, 64x128, 64x64
 static int g_opt_tail = 1;      // cut the tiles of a less-than-half-full last round into 256x128 halves (persistent 256x256 grid)
 static int g_opt_skinny = 1;    // M <= 16 NT problems (decode) on the weight-streaming kernel
+static int g_opt_gemv_stream = 1;   // ... in its ring-buffered form (gemv_stream_kernel); 0 = gemm_skinny_kernel (A/B)
+static int g_opt_gemv_nt = 0;       // non-temporal policy on the decode kernels' weight loads (A/B: tools/gemv_bench.py)
+static int g_opt_gemv_wgs = 0;      // persistent workgroups per CU of gemv_stream_kernel (0 = what fits: 2, or 1 with a large x)
 static int g_opt_small = -1;    // experiments: force the DMA variant for problems that do not fill the chip (-1 = heuristic)
 // problems too small for the 256-wide tiles (ViT-L/14 on 4 images = 1028 rows, projector): these are latency-bound, so
 // the tile is chosen by how many workgroups it yields (tools/gemm_bench.py --small: 64x128 wins up to ~96 tiles of
@@ -1533,6 +1584,9 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!strcmp(name, "adamw_blocks")) { if (value < 0) return MM_ERR_ARG; g_adamw_blocks = value; return MM_OK; }
   if (!strcmp(name, "gemm_tail")) { g_opt_tail = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_skinny")) { g_opt_skinny = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemv_stream")) { g_opt_gemv_stream = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemv_nt")) { g_opt_gemv_nt = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemv_wgs")) { g_opt_gemv_wgs = value; return MM_OK; }
   if (!strcmp(name, "gemm_small")) { if (value < -1 || value > 5) return MM_ERR_ARG; g_opt_small = value; return MM_OK; }
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_epi_pipe")) { g_opt_epi_pipe = value != 0; return MM_OK; }
@@ -1545,6 +1599,9 @@ extern "C" int mm_get_option(const char* name, int* value) {
   if (!name || !value) return MM_ERR_ARG;
   if (!strcmp(name, "gemm_tail")) { *value = g_opt_tail; return MM_OK; }
   if (!strcmp(name, "gemm_skinny")) { *value = g_opt_skinny; return MM_OK; }
+  if (!strcmp(name, "gemv_stream")) { *value = g_opt_gemv_stream; return MM_OK; }
+  if (!strcmp(name, "gemv_nt")) { *value = g_opt_gemv_nt; return MM_OK; }
+  if (!strcmp(name, "gemv_wgs")) { *value = g_opt_gemv_wgs; return MM_OK; }
   if (!strcmp(name, "gemm_small")) { *value = g_opt_small; return MM_OK; }
   if (!strcmp(name, "gemm_persist")) { *value = g_opt_persist; return MM_OK; }
   if (!strcmp(name, "gemm_epi_pipe")) { *value = g_opt_epi_pipe; return MM_OK; }
@@ -1698,22 +1755,48 @@ static int skinny_common(int dtype, int M, int K, const void* X, int ldx, const 
   return MM_OK;
 }
 
+constexpr int64_t GEMV_X_LDS_MAX = 144 * 1024;      // x rows staged in LDS (beside 8 KB of reduction scratch)
+
+static bool gemv_stream_fits(int M, int K) { return (K & 7) == 0 && (int64_t)M * K * 2 <= GEMV_X_LDS_MAX; }
+
+template <int MODE>
+static int gemv_stream_launch(const SkinnyArgs& g, unsigned nblk, hipStream_t s) {
+  if (!gemv_stream_fits(g.M, g.K)) return MM_ERR_UNSUPPORTED;
+  if (g.norm_w && (g.K > 8192 || !mm_aligned16(g.norm_w))) return MM_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)g.M * g.K * 2;
+  // persistent grid: as many workgroups as the chip holds at once (2 per CU by registers, fewer when x takes most of the LDS)
+  static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
+  const int per_cu = g_opt_gemv_wgs > 0 ? g_opt_gemv_wgs : ((lds + 17 * 1024) * 2 <= 160 * 1024 ? 2 : 1);
+  const unsigned cap = (unsigned)(ncu * per_cu);
+  const unsigned grid = nblk < cap ? nblk : cap;
+#define MM_GEMV_LAUNCH(NORM, NT)                                                                              \
+  do {                                                                                                        \
+    auto kfn = gemv_stream_kernel<MODE, NORM, NT>;                                                            \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, s, g, (int)nblk);                                     \
+  } while (0)
+  if (g.norm_w) { if (g_opt_gemv_nt) MM_GEMV_LAUNCH(true, true); else MM_GEMV_LAUNCH(true, false); }
+  else { if (g_opt_gemv_nt) MM_GEMV_LAUNCH(false, true); else MM_GEMV_LAUNCH(false, false); }
+#undef MM_GEMV_LAUNCH
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
 extern "C" int mm_decode_gateup_swiglu(int dtype, int M, int I, int K, const void* X, int ldx, const void* Wgu, int ldw, void* ACT, int ldact,
-                                       void* stream) {
+                                       const void* in_norm_w, float eps, void* stream) {
   int rc = skinny_common(dtype, M, K, X, ldx, Wgu, ldw, (int64_t)2 * I);
   if (rc != MM_OK) return rc;
   if (I <= 0 || !ACT) return MM_ERR_ARG;
   if ((I & 3) || (ldact & 3) || (((uintptr_t)ACT) & 7)) return MM_ERR_ALIGN;
   SkinnyArgs g{};
   g.M = M; g.N = 2 * I; g.K = K; g.A = (const bf16*)X; g.lda = ldx; g.B = (const bf16*)Wgu; g.ldb = ldw; g.C = (bf16*)ACT; g.ldc = ldact; g.I = I;
-  hipLaunchKernelGGL(gemm_skinny_fused_kernel<1>, dim3((unsigned)((I + 7) / 8)), dim3(512), 0, (hipStream_t)stream, g);
-  MM_CHECK_LAUNCH();
-  return MM_OK;
+  g.norm_w = (const bf16*)in_norm_w; g.eps = eps;
+  return gemv_stream_launch<1>(g, (unsigned)((I + 7) / 8), (hipStream_t)stream);
 }
 
 extern "C" int mm_decode_qkv_rope_append(int dtype, int M, int Hq, int Hkv, int D, int K, const void* X, int ldx, const void* W, int ldw,
                                          const void* bias, void* QKV, int ldqkv, const float* cos_t, const float* sin_t, void* kdst, void* vdst,
-                                         int64_t dstride, void* stream) {
+                                         int64_t dstride, const void* in_norm_w, float eps, void* stream) {
   if (Hq <= 0 || Hkv <= 0) return MM_ERR_ARG;
   const int N = (Hq + 2 * Hkv) * D;
   int rc = skinny_common(dtype, M, K, X, ldx, W, ldw, N);
@@ -1726,25 +1809,20 @@ extern "C" int mm_decode_qkv_rope_append(int dtype, int M, int Hq, int Hkv, int 
   SkinnyArgs g{};
   g.M = M; g.N = N; g.K = K; g.A = (const bf16*)X; g.lda = ldx; g.B = (const bf16*)W; g.ldb = ldw; g.C = (bf16*)QKV; g.ldc = ldqkv;
   g.bias = (const bf16*)bias; g.Hq = Hq; g.Hkv = Hkv; g.cos_t = cos_t; g.sin_t = sin_t; g.kdst = (bf16*)kdst; g.vdst = (bf16*)vdst; g.dstride = dstride;
-  hipLaunchKernelGGL(gemm_skinny_fused_kernel<2>, dim3((unsigned)(N / 16)), dim3(512), 0, (hipStream_t)stream, g);
-  MM_CHECK_LAUNCH();
-  return MM_OK;
+  g.norm_w = (const bf16*)in_norm_w; g.eps = eps;
+  return gemv_stream_launch<2>(g, (unsigned)(N / 16), (hipStream_t)stream);
 }
 
-extern "C" int mm_decode_linear_norm(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* residual, int ldr,
-                                     void* C, int ldc, const void* norm_w, float eps, void* Y, int ldy, void* counter, void* stream) {
+extern "C" int mm_decode_linear(int dtype, int M, int N, int K, const void* X, int ldx, const void* W, int ldw, const void* bias,
+                                const void* residual, int ldr, void* C, int ldc, const void* in_norm_w, float eps, void* stream) {
   int rc = skinny_common(dtype, M, K, X, ldx, W, ldw, N);
   if (rc != MM_OK) return rc;
-  if (N <= 0 || !C || !norm_w || !Y || !counter) return MM_ERR_ARG;
-  if ((N & 7) || N > 8192) return MM_ERR_UNSUPPORTED;
-  if ((ldc & 7) || (ldy & 7) || (residual && (ldr & 3)) || !mm_aligned16(C) || !mm_aligned16(Y) || !mm_aligned16(norm_w) || (((uintptr_t)counter) & 3))
-    return MM_ERR_ALIGN;
+  if (N <= 0 || !C) return MM_ERR_ARG;
+  if ((((uintptr_t)C) & 1) || ldc < N || (residual && ldr < N)) return MM_ERR_ALIGN;
   SkinnyArgs g{};
   g.M = M; g.N = N; g.K = K; g.A = (const bf16*)X; g.lda = ldx; g.B = (const bf16*)W; g.ldb = ldw; g.C = (bf16*)C; g.ldc = ldc;
-  g.residual = (const bf16*)residual; g.ldr = ldr; g.norm_w = (const bf16*)norm_w; g.eps = eps; g.Y = (bf16*)Y; g.ldy = ldy; g.counter = (unsigned*)counter;
-  hipLaunchKernelGGL(gemm_skinny_fused_kernel<0>, dim3((unsigned)((N + 15) / 16)), dim3(512), 0, (hipStream_t)stream, g);
-  MM_CHECK_LAUNCH();
-  return MM_OK;
+  g.bias = (const bf16*)bias; g.residual = (const bf16*)residual; g.ldr = ldr; g.norm_w = (const bf16*)in_norm_w; g.eps = eps;
+  return gemv_stream_launch<0>(g, (unsigned)((N + 15) / 16), (hipStream_t)stream);
 }
 
 static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
@@ -1764,6 +1842,14 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
     const int forced = g_opt_kernel ? g_opt_kernel : forced_env;
     if (forced == 0 && g_opt_skinny && layout == MM_GEMM_NT && M <= 16 && !g.swi_I && !g.rope_cols &&
         (int64_t)16 * lda * 2 < 0xFFFFFFFFll && (int64_t)16 * ldb * 2 < 0xFFFFFFFFll) {   // decode: stream W once
+      if (g_opt_gemv_stream && gemv_stream_fits(M, K) && (int64_t)N * ldb * 2 < 0xFFFFFFFFll) {   // the ring-buffered form (same bits)
+        SkinnyArgs q{};
+        q.M = M; q.N = N; q.K = K; q.A = (const bf16*)A; q.lda = lda; q.B = (const bf16*)B; q.ldb = ldb; q.C = (bf16*)C; q.ldc = ldc;
+        q.bias = (epilogue & MM_EPI_BIAS) ? (const bf16*)g.bias : nullptr;
+        q.residual = (epilogue & MM_EPI_RESIDUAL) ? (const bf16*)g.residual : nullptr;
+        q.ldr = ldr; q.epi = epilogue;
+        return gemv_stream_launch<0>(q, (unsigned)((N + 15) / 16), s);
+      }
       dim3 grid((unsigned)((N + 15) / 16)), block(512);
       hipLaunchKernelGGL(gemm_skinny_kernel, grid, block, 0, s, g);
       MM_CHECK_LAUNCH();

@@ -155,39 +155,39 @@ def gemm_rope_fwd(x2d, w, bias, rope_cols, D, cos, sin):
 
 
 # ---- decode-step fusions (M = batch <= 16 rows; see include/mm_hip.h) ----------------------------------------------------------
-def decode_gateup_swiglu(x2d, wgu, I):
+def decode_fits(M, K):
+    """x (M rows of K bf16) must fit the weight-streaming kernel's LDS stage."""
+    return K % 8 == 0 and M * K * 2 <= 144 * 1024
+
+
+def decode_gateup_swiglu(x2d, wgu, I, norm_w=None, eps=0.0):
+    """act [M, I] = silu(x' Wg^T) * (x' Wu^T), x' = rmsnorm(x) * norm_w when norm_w is given."""
     M, K = x2d.shape
     act = torch.empty((M, I), dtype=x2d.dtype, device=x2d.device)
-    call("mm_decode_gateup_swiglu", dt(x2d), M, I, K, _p(x2d), x2d.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), _stream())
+    call("mm_decode_gateup_swiglu", dt(x2d), M, I, K, _p(x2d), x2d.stride(0), _p(wgu), wgu.stride(0), _p(act), act.stride(0), _p(norm_w), float(eps),
+         _stream())
     return act
 
 
-def decode_qkv_rope_append(x2d, w, bias, Hq, Hkv, D, cos, sin, kcache, vcache, pos):
-    """qkv [B, (Hq+2Hkv)*D] = x @ w^T (+ bias) with RoPE on q / k and the append of roped k / v to cache[:, pos]."""
+def decode_qkv_rope_append(x2d, w, bias, Hq, Hkv, D, cos, sin, kcache, vcache, pos, norm_w=None, eps=0.0):
+    """qkv [B, (Hq+2Hkv)*D] = x' @ w^T (+ bias) with RoPE on q / k and the append of roped k / v to cache[:, pos]."""
     M, K = x2d.shape
     assert kcache.stride(3) == 1 and kcache.stride(2) == D and vcache.stride(2) == D and kcache.stride(0) == vcache.stride(0)
     qkv = torch.empty((M, (Hq + 2 * Hkv) * D), dtype=x2d.dtype, device=x2d.device)
     call("mm_decode_qkv_rope_append", dt(x2d), M, Hq, Hkv, D, K, _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(qkv), qkv.stride(0),
-         _p(cos), _p(sin), _p(kcache[:, pos]), _p(vcache[:, pos]), kcache.stride(0), _stream())
+         _p(cos), _p(sin), _p(kcache[:, pos]), _p(vcache[:, pos]), kcache.stride(0), _p(norm_w), float(eps), _stream())
     return qkv
 
 
-_decode_counters = {}
-
-
-def decode_linear_norm(x2d, w, residual, norm_w, eps):
-    """-> (c, y): c = x @ w^T + residual, y = rmsnorm(c) * norm_w (the next projection's input), one launch."""
+def decode_linear(x2d, w, bias=None, residual=None, norm_w=None, eps=0.0, ldc_pad=False):
+    """c [M, N] = x' @ w^T (+ bias) (+ residual), x' = rmsnorm(x) * norm_w when norm_w is given; ldc_pad: row stride padded to 64."""
     M, K = x2d.shape
     N = w.shape[0]
-    dev = x2d.device
-    cnt = _decode_counters.get(dev)
-    if cnt is None:
-        cnt = _decode_counters[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-    c = torch.empty((M, N), dtype=x2d.dtype, device=dev)
-    y = torch.empty((M, N), dtype=x2d.dtype, device=dev)
-    call("mm_decode_linear_norm", dt(x2d), M, N, K, _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(residual),
-         residual.stride(0) if residual is not None else 0, _p(c), N, _p(norm_w), float(eps), _p(y), N, _p(cnt), _stream())
-    return c, y
+    ld = (N + 63) // 64 * 64 if ldc_pad else N
+    buf = torch.empty((M, ld), dtype=x2d.dtype, device=x2d.device)
+    call("mm_decode_linear", dt(x2d), M, N, K, _p(x2d), x2d.stride(0), _p(w), w.stride(0), _p(bias), _p(residual),
+         residual.stride(0) if residual is not None else 0, _p(buf), ld, _p(norm_w), float(eps), _stream())
+    return buf[:, :N] if ld != N else buf
 
 
 def decode_fusions():      # A/B switch (tools/decode_bench.py): MM_DECODE_FUSED=0 -> the separate launches

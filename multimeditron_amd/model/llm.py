@@ -131,20 +131,21 @@ class DecoderLayer(nn.Module):
         return K.linear_fwd(act, m.down_proj.weight, residual=x)
 
     @torch.no_grad()
-    def decode_step_fused(self, x, h, cos, sin, key_mask, B, cache, next_norm):
+    def decode_step_fused(self, x, cos, sin, key_mask, B, cache):
         """The same decode step with the tiny launches folded into the weight-streaming GEMMs (round 3; csrc/mm_gemm.hip
-        gemm_skinny_fused_kernel): q|k|v + RoPE + cache append, o_proj + residual + the post-attention RMSNorm, gate|up + SwiGLU,
-        down_proj + residual + the NEXT layer's input RMSNorm (`next_norm`: that layer's input_layernorm, or the model's final norm).
-        x = residual stream, h = this layer's already normalised input.  -> (x, h of the next layer).  Same bits as decode_step."""
+        gemv_stream_kernel): input RMSNorm + q|k|v + RoPE + cache append, o_proj + residual, post-attention RMSNorm + gate|up +
+        SwiGLU, down_proj + residual -- 6 launches with the two attention kernels, none of them a norm.  x = residual stream in
+        and out.  Same bits as decode_step."""
         a, m = self.self_attn, self.mlp
         Hq, Hkv, D = a.Hq, a.Hkv, a.D
-        qkv = K.decode_qkv_rope_append(h, a._wqkv.tensor(), a._bqkv.tensor() if a._bqkv is not None else None, Hq, Hkv, D, cos, sin,
-                                       cache.k, cache.v, cache.len)
+        n1, n2 = self.input_layernorm, self.post_attention_layernorm
+        qkv = K.decode_qkv_rope_append(x, a._wqkv.tensor(), a._bqkv.tensor() if a._bqkv is not None else None, Hq, Hkv, D, cos, sin,
+                                       cache.k, cache.v, cache.len, norm_w=n1.weight, eps=n1.eps)
         cache.len += 1
         o = K.attn_decode(qkv[:, : Hq * D].view(B, Hq, D), cache.k[:, : cache.len], cache.v[:, : cache.len], key_mask, D ** -0.5)
-        x, h2 = K.decode_linear_norm(o.view(B, Hq * D), a.o_proj.weight, x, self.post_attention_layernorm.weight, self.post_attention_layernorm.eps)
-        act = K.decode_gateup_swiglu(h2, m._wgu.tensor(), m.I)
-        return K.decode_linear_norm(act, m.down_proj.weight, x, next_norm.weight, next_norm.eps)
+        x = K.decode_linear(o.view(B, Hq * D), a.o_proj.weight, residual=x)
+        act = K.decode_gateup_swiglu(x, m._wgu.tensor(), m.I, norm_w=n2.weight, eps=n2.eps)
+        return K.decode_linear(act, m.down_proj.weight, residual=x)
 
     def can_decode_step(self, x, B, S, cache):
         a = self.self_attn
@@ -153,8 +154,9 @@ class DecoderLayer(nn.Module):
 
     def can_decode_step_fused(self, x, B, S, cache):
         a = self.self_attn
-        return (self.can_decode_step(x, B, S, cache) and a.D == 128 and K.decode_fusions() and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192
-                and self.mlp.I % 4 == 0)
+        return (self.can_decode_step(x, B, S, cache) and a.D == 128 and K.decode_fusions() and x.shape[-1] <= 8192 and self.mlp.I % 4 == 0
+                and K.decode_fits(B, x.shape[-1]) and K.decode_fits(B, self.mlp.I) and K.decode_fits(B, a.Hq * a.D)
+                and a.o_proj.bias is None and self.mlp.down_proj.bias is None and self.input_layernorm.bias is None)
 
     def forward(self, x, cos, sin, key_mask, B, S, cache=None):
         if self.can_decode_step(x, B, S, cache):
@@ -309,13 +311,15 @@ class CausalLM(nn.Module):
         if not x.is_contiguous():
             x = x.contiguous()
         layers = self.model.layers
+        fused_head = False
         if cache and len(layers) and all(layer.can_decode_step_fused(x, B, S, cache[i]) for i, layer in enumerate(layers)):
-            # decode step: every RMSNorm rides on the GEMM in front of it (DecoderLayer.decode_step_fused); only the first is a launch
-            h, _ = K.rmsnorm_fwd(x, layers[0].input_layernorm.weight, layers[0].input_layernorm.eps)
+            # decode step: every RMSNorm is applied by the projection that consumes it (DecoderLayer.decode_step_fused), the final
+            # norm by lm_head below
             for i, layer in enumerate(layers):
-                nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else self.model.norm
-                x, h = layer.decode_step_fused(x, h, cos, sin, key_mask, B, cache[i], nxt)
-            x = h                                            # = final norm of the last residual stream
+                x = layer.decode_step_fused(x, cos, sin, key_mask, B, cache[i])
+            fused_head = self.lm_head.bias is None and self.model.norm.bias is None       # S == 1: logits_to_keep keeps the one row
+            if not fused_head:
+                x, _ = self.model.norm(x)
         else:
             for i, layer in enumerate(layers):
                 x = layer(x, cos, sin, key_mask, B, S, cache=cache[i] if cache else None)
@@ -331,7 +335,10 @@ class CausalLM(nn.Module):
             Sk = logits_to_keep
         else:
             Sk = S
-        logits2d = self.lm_head(x, ldc_pad=True)                 # [B*Sk, V] view, row stride padded to 64
+        if fused_head:
+            logits2d = K.decode_linear(x, self.lm_head.weight, norm_w=self.model.norm.weight, eps=self.model.norm.eps, ldc_pad=True)
+        else:
+            logits2d = self.lm_head(x, ldc_pad=True)             # [B*Sk, V] view, row stride padded to 64
         loss = None
         if rows is not None:
             loss = Fm.causal_lm_loss(logits2d, V, rows.labels)

@@ -226,54 +226,94 @@ def test_gemm_skinny_decode(K, shape):
     assert rel(out2.float(), ref2) < TOL[dtype]
 
 
+def _old_skinny(fn):
+    """Run fn with M <= 16 GEMMs on the round-2 weight-streaming kernel (gemm_skinny_kernel) instead of its ring-buffered form."""
+    from multimeditron_amd._lib import lib
+    lib().mm_set_option(b"gemv_stream", 0)
+    try:
+        return fn()
+    finally:
+        lib().mm_set_option(b"gemv_stream", 1)
+
+
+@pytest.mark.parametrize("norm", [False, True])
 @pytest.mark.parametrize("M,H,I", [(4, 4096, 14336), (1, 512, 1000), (16, 3584, 2368), (7, 1088, 72)])
-def test_decode_fused_gateup_swiglu_bit_identical(K, M, H, I):
-    """mm_decode_gateup_swiglu = weight-streaming gate|up GEMM + mm_swiglu_fwd, bit for bit (same K split, same rounding points)."""
+def test_decode_fused_gateup_swiglu_bit_identical(K, M, H, I, norm):
+    """mm_decode_gateup_swiglu = [mm_rmsnorm_fwd +] weight-streaming gate|up GEMM + mm_swiglu_fwd, bit for bit (same K split, same
+    rounding points) -- against the separate launches on BOTH forms of the streaming kernel."""
     x = rnd((M, H), torch.bfloat16, 301).cuda()
     wgu = rnd((2 * I, H), torch.bfloat16, 302, 0.05).cuda()
-    fused = K.decode_gateup_swiglu(x, wgu, I)
-    two = K.swiglu_fwd(K.linear_fwd(x, wgu), I)
-    assert torch.equal(fused, two)
-    g = x.float() @ wgu.float().t()
+    nw = (1.0 + 0.1 * rnd((H,), torch.float32, 303)).to(torch.bfloat16).cuda() if norm else None
+    fused = K.decode_gateup_swiglu(x, wgu, I, norm_w=nw, eps=1e-5)
+    h = K.rmsnorm_fwd(x, nw, 1e-5)[0] if norm else x
+    two = K.swiglu_fwd(K.linear_fwd(h, wgu), I)
+    old = _old_skinny(lambda: K.swiglu_fwd(K.linear_fwd(h, wgu), I))
+    assert torch.equal(fused, two) and torch.equal(fused, old)
+    g = h.float() @ wgu.float().t()
     assert rel(fused.float(), F.silu(g[:, :I]) * g[:, I:]) < 2e-2
 
 
+@pytest.mark.parametrize("norm", [False, True])
 @pytest.mark.parametrize("M,Hq,Hkv,Kd,bias", [(4, 32, 8, 4096, False), (1, 4, 1, 512, True), (16, 28, 4, 3584, True), (3, 3, 2, 200, False)])
-def test_decode_fused_qkv_rope_append_bit_identical(K, M, Hq, Hkv, Kd, bias):
-    """mm_decode_qkv_rope_append = weight-streaming q|k|v GEMM + mm_rope_append (RoPE on q / k, roped k and v into the cache row)."""
+def test_decode_fused_qkv_rope_append_bit_identical(K, M, Hq, Hkv, Kd, bias, norm):
+    """mm_decode_qkv_rope_append = [mm_rmsnorm_fwd +] weight-streaming q|k|v GEMM + mm_rope_append (RoPE on q / k, roped k and v
+    into the cache row)."""
     D, Smax, pos = 128, 9, 5
     N = (Hq + 2 * Hkv) * D
     x = rnd((M, Kd), torch.bfloat16, 311).cuda()
     w = rnd((N, Kd), torch.bfloat16, 312, 0.05).cuda()
     b = rnd((N,), torch.bfloat16, 313, 0.5).cuda() if bias else None
+    nw = (1.0 + 0.1 * rnd((Kd,), torch.float32, 315)).to(torch.bfloat16).cuda() if norm else None
     ang = rnd((M, D // 2), torch.float32, 314, 3.0)
     cos, sin = torch.cos(ang).cuda(), torch.sin(ang).cuda()
     kc1, vc1 = (torch.full((M, Smax, Hkv, D), 7.0, dtype=torch.bfloat16, device="cuda") for _ in range(2))
     kc2, vc2 = kc1.clone(), vc1.clone()
-    fused = K.decode_qkv_rope_append(x, w, b, Hq, Hkv, D, cos, sin, kc1, vc1, pos)
-    two = K.linear_fwd(x, w, bias=b)
+    fused = K.decode_qkv_rope_append(x, w, b, Hq, Hkv, D, cos, sin, kc1, vc1, pos, norm_w=nw, eps=1e-6)
+    h = K.rmsnorm_fwd(x, nw, 1e-6)[0] if norm else x
+    two = _old_skinny(lambda: K.linear_fwd(h, w, bias=b))
     K.rope_append_(two, M, Hq, Hkv, D, cos, sin, kc2, vc2, pos)
     torch.cuda.synchronize()
     assert torch.equal(fused, two) and torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
     assert torch.equal(kc1[:, pos].reshape(M, -1), fused[:, Hq * D:(Hq + Hkv) * D]) and bool((kc1[:, pos - 1] == 7.0).all())
 
 
-@pytest.mark.parametrize("M,N,Kd", [(4, 4096, 4096), (4, 4096, 14336), (1, 512, 200), (16, 3584, 1000), (5, 8192, 256)])
-def test_decode_fused_linear_norm_bit_identical(K, M, N, Kd):
-    """mm_decode_linear_norm = weight-streaming GEMM (+ residual) + mm_rmsnorm_fwd: the RMSNorm is done by the workgroup that finishes
-    last (arrival counter, agent-scope release / acquire), with the separate kernel's own arithmetic: same bits, launch after launch
-    (the counter must come back to zero every time)."""
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("M,N,Kd", [(4, 4096, 4096), (4, 4096, 14336), (1, 512, 200), (16, 3584, 1000), (5, 8192, 256), (4, 128258, 4096), (3, 130, 8192)])
+def test_decode_linear_bit_identical(K, M, N, Kd, norm):
+    """mm_decode_linear = [mm_rmsnorm_fwd +] weight-streaming GEMM (+ residual), the norm applied while x is staged into LDS with the
+    separate kernel's own arithmetic: same bits as the two launches, on both forms of the streaming kernel, launch after launch;
+    ragged N and the padded row stride of the logits."""
+    if norm and Kd > 8192:
+        pytest.skip("norm prologue holds rows of <= 8192")
     x = rnd((M, Kd), torch.bfloat16, 321).cuda()
     w = rnd((N, Kd), torch.bfloat16, 322, 0.05).cuda()
-    res = rnd((M, N), torch.bfloat16, 323).cuda()
-    nw = (1.0 + 0.1 * rnd((N,), torch.float32, 324)).to(torch.bfloat16).cuda()
-    c_ref = K.linear_fwd(x, w, residual=res)
-    y_ref, _ = K.rmsnorm_fwd(c_ref, nw, 1e-5)
-    for it in range(25):
-        c, y = K.decode_linear_norm(x, w, res, nw, 1e-5)
+    rp = torch.zeros(M, (N + 63) // 64 * 64, dtype=torch.bfloat16)
+    rp[:, :N] = rnd((M, N), torch.bfloat16, 323)
+    res = rp.cuda()[:, :N]                                                 # row stride padded: mm_gemm wants ldr % 4 == 0
+    nw = (1.0 + 0.1 * rnd((Kd,), torch.float32, 324)).to(torch.bfloat16).cuda() if norm else None
+    h = K.rmsnorm_fwd(x, nw, 1e-5)[0] if norm else x
+    c_ref = K.linear_fwd(h, w, residual=res, ldc_pad=True)                # padded row stride: mm_gemm wants ldc % 4 == 0
+    c_old = _old_skinny(lambda: K.linear_fwd(h, w, residual=res, ldc_pad=True))
+    assert torch.equal(c_ref, c_old)
+    for it in range(3):
+        c = K.decode_linear(x, w, residual=res, norm_w=nw, eps=1e-5, ldc_pad=(it > 0))      # any row stride >= N
         assert torch.equal(c, c_ref), it
-        assert torch.equal(y, y_ref), it
-    assert int(K._decode_counters[x.device][0]) == 0
+    cp = K.decode_linear(x, w, norm_w=nw, eps=1e-5, ldc_pad=True)
+    assert cp.stride(0) % 64 == 0 and torch.equal(cp, _old_skinny(lambda: K.linear_fwd(h, w, ldc_pad=True)))
+    assert rel(cp.float(), h.float() @ w.float().t()) < 2e-2
+
+
+def test_decode_linear_refuses_what_does_not_fit(K):
+    """x must fit the kernel's LDS stage (M * K * 2 <= 144 KB): a larger problem is refused (the caller keeps the separate launches;
+    plain mm_gemm falls back to gemm_skinny_kernel by itself)."""
+    from multimeditron_amd._lib import MMHipError
+    x = rnd((16, 14336), torch.bfloat16, 331).cuda()
+    w = rnd((256, 14336), torch.bfloat16, 332, 0.05).cuda()
+    assert not K.decode_fits(16, 14336) and K.decode_fits(4, 14336)
+    with pytest.raises(MMHipError):
+        K.decode_linear(x, w)
+    out = K.linear_fwd(x, w)
+    assert rel(out.float(), x.float() @ w.float().t()) < 2e-2
 
 
 def test_rope_append(K):
