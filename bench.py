@@ -43,13 +43,14 @@ PEAK_HBM_GBS = 8000.0
 
 def flops_per_sample(llm, vis, S, n_img, vocab, hidden_proj, lm_head_rows=None):
     """Algorithmic forward FLOPs per sample: 2*params*tokens for linears, 4*T^2*d*L attention (causal
-    halved).  fwd+bwd (FULL) = 3x.  lm_head_rows: rows per sample that go through lm_head (default: all S, as HF computes;
-    the Trainer runs lm_head on the labelled rows only -- EXECUTED flops count those)."""
+    halved).  fwd+bwd (FULL) = 3x.  lm_head_rows: rows per sample that go through lm_head and through the last layer's o_proj + MLP
+    (default: all S, as HF computes; the Trainer runs them on the labelled rows only -- EXECUTED flops count those)."""
     H, I, L = llm["hidden_size"], llm["intermediate_size"], llm["num_hidden_layers"]
     hd = llm["head_dim"]
     qo, kv = llm["num_attention_heads"] * hd, llm["num_key_value_heads"] * hd
     lin = L * (H * (qo + 2 * kv) + qo * H + 3 * H * I)
-    f = 2.0 * lin * S + 2.0 * H * vocab * (S if lm_head_rows is None else lm_head_rows) + 0.5 * 4.0 * S * S * qo * L
+    rows = S if lm_head_rows is None else lm_head_rows       # ... and o_proj + MLP of the LAST layer (DecoderLayer.forward `rows`)
+    f = 2.0 * lin * S - 2.0 * (qo * H + 3 * H * I) * (S - rows) + 2.0 * H * vocab * rows + 0.5 * 4.0 * S * S * qo * L
     Dv, Iv, Lv = vis["hidden_size"], vis["intermediate_size"], vis["num_hidden_layers"]
     P = (vis["image_size"] // vis["patch_size"]) ** 2
     T = P + (0 if vis.get("kind") == "siglip" else 1)       # SigLIP has no CLS token
@@ -485,7 +486,7 @@ def main():
             step_tf = value / world * fps_exec / 1e12
             out["config"]["flops_per_sample_fwd_bwd"] = fps_exec
             if rows is not None:
-                out["config"]["loss_rows"] = (f"final norm, lm_head and cross-entropy on the {rows.n} of {rows.total} rows whose shifted label is "
+                out["config"]["loss_rows"] = (f"last layer's o_proj + MLP, final norm, lm_head and cross-entropy on the {rows.n} of {rows.total} rows whose shifted label is "
                                               f"not -100 (same loss and gradients; MM_LOSS_ROWS=0 computes every row as HF does: "
                                               f"{fps:.6g} flops/sample); whole_step_* count the executed flops")
         roof = None

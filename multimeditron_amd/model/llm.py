@@ -158,7 +158,11 @@ class DecoderLayer(nn.Module):
                 and K.decode_fits(B, x.shape[-1]) and K.decode_fits(B, self.mlp.I) and K.decode_fits(B, a.Hq * a.D)
                 and a.o_proj.bias is None and self.mlp.down_proj.bias is None and self.input_layernorm.bias is None)
 
-    def forward(self, x, cos, sin, key_mask, B, S, cache=None):
+    def forward(self, x, cos, sin, key_mask, B, S, cache=None, rows=None):
+        """rows (functional.LossRows, LAST layer of a training forward only): nothing after this layer's attention reads the
+        rows that carry no label -- their hidden states feed no later layer and no loss term -- so o_proj, the post-attention norm
+        and the MLP run on the labelled rows alone and the layer returns [rows.n, H].  (Keys and values come from every row, so
+        attention itself is computed in full.)  Same loss, same gradients."""
         if self.can_decode_step(x, B, S, cache):
             return self.decode_step(x, cos, sin, key_mask, B, cache)
         a = self.self_attn
@@ -169,6 +173,8 @@ class DecoderLayer(nn.Module):
         else:
             qkv = Fm.linear(h, a._wqkv, a._bqkv, dummy=grad_dummy(a.q_proj.weight))
             o = cache.attend(qkv, cos, sin, key_mask, B, S, a)
+        if rows is not None:
+            o, x = Fm.rows_select(o, rows), Fm.rows_select(x, rows)
         x = a.o_proj(o, residual=x)
         h, x = self.post_attention_layernorm(x)
         return Fm.swiglu_mlp(h, self.mlp._wgu, self.mlp.down_proj.weight, self.mlp.I, residual=x,
@@ -321,12 +327,14 @@ class CausalLM(nn.Module):
             if not fused_head:
                 x, _ = self.model.norm(x)
         else:
+            # training step (Trainer.compute_loss hands over `loss_rows`): the loss and every gradient depend only on the rows whose
+            # shifted label is not -100 (HF:loss/loss_utils.py:36-71 ignores the others; their dlogits are exactly zero), so the
+            # final norm, lm_head and the loss -- and what follows attention in the LAST layer -- run on those rows alone;
+            # `logits` is then not returned
+            last = len(layers) - 1
             for i, layer in enumerate(layers):
-                x = layer(x, cos, sin, key_mask, B, S, cache=cache[i] if cache else None)
-            if rows is not None:
-                # training step (Trainer.compute_loss hands over `loss_rows`): the loss and every gradient depend only on the
-                # rows whose shifted label is not -100 (HF:loss/loss_utils.py:36-71 ignores the others; their dlogits are exactly
-                # zero), so the final norm, lm_head and the loss run on those rows alone; `logits` is then not returned
+                x = layer(x, cos, sin, key_mask, B, S, cache=cache[i] if cache else None, rows=rows if i == last else None)
+            if rows is not None and not len(layers):
                 x = Fm.rows_select(x, rows)
             x, _ = self.model.norm(x)
         V = self.config.vocab_size
