@@ -2416,6 +2416,134 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(DecodeArgs a) 
   }
 }
 
+// D = 128, G <= 4 query heads per key/value head: the same slice of the same (batch, kv head), with the scores on the MATRIX
+// cores.  attn_decode_partial_kernel takes q.k as 8 FMAs per lane plus a 4-step cross-lane sum per (key, head): 64 ds_bpermute
+// per 16 keys and wave, and its time did not move between 256 and 1536 workgroups (17 us per launch for 34 MB of cache: a
+// throughput bound of its own making).  Here a wave takes 16 keys at a time:
+//   S[16 keys x G] = K[16 x 128] Q^T: 4 x mfma_16x16x32 with K rows as the first operand (a lane loads 16 bytes of key l & 15) and
+//   the G query rows as the second; lane (g = l & 15, kq = l >> 4) then holds the scores of keys 4 kq .. 4 kq + 3 for head g;
+//   block softmax (max over the 16 keys: 4 registers and two cross-row exchanges), running (m, l) per head;
+//   P V on the vector ALU with V rows as they lie in memory: lane (sub = l & 15, kq) holds 8 dims of keys 4 kq + u, and the
+//   probabilities it needs sit in lane g of ITS OWN 16-lane row: one DPP row broadcast each (no LDS traffic).
+// Same record format (m, l, o[D]) per slice: attn_decode_merge_kernel is unchanged.
+__device__ __forceinline__ float row_bcast(float x, int lane_in_row) {          // value of lane `lane_in_row` of this lane's 16-lane row
+  return __shfl(x, (int)(threadIdx.x & 48u) | lane_in_row, 64);
+}
+template <int N>
+__device__ __forceinline__ float row_bcast_dpp(float x) {                        // the same as ONE v_mov_b32 dpp row_newbcast:N (gfx90a+)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + N, 0xf, 0xf, false));
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void attn_decode_partial128_mfma_kernel(DecodeArgs a) {
+  constexpr int D = 128;
+  static_assert(G >= 1 && G <= 4, "row-broadcast unrolling and the LDS budget below are written for G <= 4");
+  __shared__ float red_o[4][4][G][D];          // [wave][kq][head][d]
+  __shared__ float red_ml[4][G][2];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = l & 15, kq = l >> 4;
+  const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+  const bf16* Kb = (const bf16*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const bf16* Vb = (const bf16*)a.v + b * a.v_sb + hkv * a.v_sh;
+  const int kbeg = split * a.chunk, kend = min(a.Skv, kbeg + a.chunk);
+  const float sc = a.scale * LOG2E;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < G) qf[ks] = *(const bf16x8*)((const bf16*)a.q + b * a.q_sb + (hkv * G + row) * a.q_sh + ks * 32 + kq * 8);
+  }
+  float o[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  bf16x8 kf[4], vf[4];
+  auto load_block = [&](int k0) {
+    const int kk = min(k0 + row, kend - 1);                       // clamp: a valid address, the score is masked below
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)(Kb + (int64_t)kk * a.k_ss + ks * 32 + kq * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kv = min(k0 + 4 * kq + u, kend - 1);
+      vf[u] = *(const bf16x8*)(Vb + (int64_t)kv * a.v_ss + row * 8);
+    }
+  };
+  int k0 = kbeg + w * 16;
+  if (k0 < kend) load_block(k0);
+  for (; k0 < kend; k0 += 64) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], acc, 0, 0, 0);
+    float vx[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vx[u][j] = (float)vf[u][j];
+    const int kcur = k0;
+    if (k0 + 64 < kend) load_block(k0 + 64);                      // the next block streams in under the softmax and the P V sums
+    float sv[4], bm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kcur + 4 * kq + r;
+      bool ok = key < kend;
+      if (ok && a.kmask) ok = a.kmask[(int64_t)b * a.Skv + key] != 0;
+      sv[r] = ok ? acc[r] * sc : -INFINITY;
+      bm = fmaxf(bm, sv[r]);
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m_run, bm);
+    const float alpha = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m_run - mn);
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sv[r] - mn);
+    l_run = l_run * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
+    m_run = mn;
+#define MM_DEC_HEAD(g)                                                              \
+    if constexpr (g < G) {                                                          \
+      const float ag = row_bcast_dpp<g>(alpha);                                     \
+      const float p0 = row_bcast_dpp<g>(p[0]), p1 = row_bcast_dpp<g>(p[1]);         \
+      const float p2 = row_bcast_dpp<g>(p[2]), p3 = row_bcast_dpp<g>(p[3]);         \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                               \
+        float t = o[g][j] * ag;                                                     \
+        t = __builtin_fmaf(p0, vx[0][j], t);                                        \
+        t = __builtin_fmaf(p1, vx[1][j], t);                                        \
+        t = __builtin_fmaf(p2, vx[2][j], t);                                        \
+        o[g][j] = __builtin_fmaf(p3, vx[3][j], t);                                  \
+      }                                                                             \
+    }
+    MM_DEC_HEAD(0) MM_DEC_HEAD(1) MM_DEC_HEAD(2) MM_DEC_HEAD(3)
+#undef MM_DEC_HEAD
+  }
+  // this wave's partial: o per (kq row, head), (m, l) per head (l summed over the 4 rows; m is the same in all of them)
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red_o[w][kq][g][row * 8 + j] = o[g][j];
+  float lt = l_run + __shfl_xor(l_run, 16, 64);
+  lt += __shfl_xor(lt, 32, 64);
+  if (kq == 0 && row < G) { red_ml[w][row][0] = m_run; red_ml[w][row][1] = lt; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * D; i += 256) {
+    const int g = i / D, d = i % D;
+    float mn = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) mn = fmaxf(mn, red_ml[ww][g][0]);
+    float ltot = 0.f, ot = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const float al = mn == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(red_ml[ww][g][0] - mn);
+      ltot += red_ml[ww][g][1] * al;
+      ot += ((red_o[ww][0][g][d] + red_o[ww][1][g][d]) + (red_o[ww][2][g][d] + red_o[ww][3][g][d])) * al;
+    }
+    float* rec = a.ws + (((int64_t)b * a.Hq + hkv * G + g) * a.nsplit + split) * (D + 2);
+    rec[2 + d] = ot;
+    if (d == 0) { rec[0] = mn; rec[1] = ltot; }
+  }
+}
+
 template <int D>
 __global__ void attn_decode_merge_kernel(const float* ws, int nsplit, bf16* out) {
   const int row = blockIdx.x, d = threadIdx.x;          // row = b * Hq + hq
@@ -2431,6 +2559,8 @@ int g_attn_q_issue = 4;       // waves issuing the K/V DMA in attn_fwd128q_kerne
 int g_attn_q_rd = 4;          // fragment ring depth of attn_fwd128q_kernel ("attn_q_rd": 4, 6 or 8)
 int g_attn_diag = 0;          // AttnArgs::diag ("attn_diag")
 int g_attn_q_prio = 1;        // s_setprio policy of the out-of-phase kernels (AttnArgs::prio; "attn_q_prio")
+int g_attn_decode_mfma = 1;   // D = 128, G <= 4 decode slices with the scores on MFMA (mm_set_option "attn_decode_mfma"; 0 = attn_decode_partial_kernel)
+int g_attn_decode_wgs = 768;  // workgroups mm_attn_decode_splits aims at (~3 per CU; mm_set_option "attn_decode_wgs")
 int g_attn_dkv_pair = 1;      // balanced paired dK/dV kernel (mm_set_option "attn_dkv_pair"; 0 = one key block per workgroup)
 int g_attn_issue_waves = 4;   // waves issuing the K/V DMA in the 8-wave D=128 kernels (mm_set_option "attn_issue_waves")
 
@@ -2549,6 +2679,8 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
 
 int mm_attn_option(const char* name, int value) {   // reached through mm_set_option (mm_gemm.hip)
   if (!strcmp(name, "attn_dkv_pair")) { g_attn_dkv_pair = value != 0; return MM_OK; }
+  if (!strcmp(name, "attn_decode_mfma")) { g_attn_decode_mfma = value != 0; return MM_OK; }
+  if (!strcmp(name, "attn_decode_wgs")) { if (value < 1) return MM_ERR_ARG; g_attn_decode_wgs = value; return MM_OK; }
   if (!strcmp(name, "attn_fwd_pf")) { g_attn_fwd_pf = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_fwd_q")) { g_attn_fwd_q = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_q_prio")) { g_attn_q_prio = value; return MM_OK; }
@@ -2638,7 +2770,7 @@ extern "C" int mm_attn_bwd(int dtype, const void* q, const void* k, const void* 
 
 extern "C" int mm_attn_decode_splits(int B, int Hkv, int Skv) {
   if (B <= 0 || Hkv <= 0 || Skv <= 0) return 1;
-  int n = (768 + B * Hkv - 1) / (B * Hkv);          // ~3 workgroups per CU
+  int n = (g_attn_decode_wgs + B * Hkv - 1) / (B * Hkv);          // ~3 workgroups per CU
   const int cap = (Skv + 63) / 64;                  // at least 64 keys per slice
   if (n > cap) n = cap;
   return n < 1 ? 1 : n;
@@ -2664,7 +2796,13 @@ extern "C" int mm_attn_decode(int dtype, const void* q, const void* k, const voi
 #define MM_DEC_G(DD)                                                                                          \
   switch (G) { case 1: MM_DEC(DD, 1); break; case 2: MM_DEC(DD, 2); break; case 4: MM_DEC(DD, 4); break;     \
                case 7: MM_DEC(DD, 7); break; default: MM_DEC(DD, 8); break; }
-  if (D == 128) { MM_DEC_G(128) } else { MM_DEC_G(64) }
+  if (D == 128 && G <= 4 && !sync && g_attn_decode_mfma) {           // scores on the matrix cores (two-launch form only)
+    switch (G) {
+      case 1: hipLaunchKernelGGL(attn_decode_partial128_mfma_kernel<1>, grid, block, 0, s, a); break;
+      case 2: hipLaunchKernelGGL(attn_decode_partial128_mfma_kernel<2>, grid, block, 0, s, a); break;
+      default: hipLaunchKernelGGL(attn_decode_partial128_mfma_kernel<4>, grid, block, 0, s, a); break;
+    }
+  } else if (D == 128) { MM_DEC_G(128) } else { MM_DEC_G(64) }
 #undef MM_DEC_G
 #undef MM_DEC
   MM_CHECK_LAUNCH();

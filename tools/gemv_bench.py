@@ -63,6 +63,13 @@ for wgs in (1, 2, 3):
     timed("norm + gate|up + SwiGLU", lambda i: K.decode_gateup_swiglu(x, w_gu[i], I, norm_w=nw, eps=1e-5), w_gu[0].numel() * 2)
     timed("down + residual", lambda i: K.decode_linear(act, w_d[i], residual=x), w_d[0].numel() * 2)
 lib().mm_set_option(b"gemv_wgs", 0)
+for wgs in (256, 512, 768, 1024, 1536):
+    lib().mm_set_option(b"attn_decode_wgs", wgs)
+    timed(f"attention, ~{wgs} workgroups", lambda i: K.attn_decode(q, kc[i][:, :S], vc[i][:, :S], None, D ** -0.5), 2 * B * S * Hkv * D * 2)
+lib().mm_set_option(b"attn_decode_wgs", 768)
+lib().mm_set_option(b"attn_decode_mfma", 0)
+timed("attention, scores on the vector ALU (round-2 slice kernel)", lambda i: K.attn_decode(q, kc[i][:, :S], vc[i][:, :S], None, D ** -0.5), 2 * B * S * Hkv * D * 2)
+lib().mm_set_option(b"attn_decode_mfma", 1)
 lib().mm_set_option(b"gemv_stream", 0)
 timed("round-2 kernel: plain o_proj", lambda i: K.linear_fwd(x, w_o[i]), w_o[0].numel() * 2)
 timed("round-2 kernel: plain down", lambda i: K.linear_fwd(act, w_d[i]), w_d[0].numel() * 2)
