@@ -252,6 +252,11 @@ int mm_ce_bwd(int dtype, const void* logits, int T, int V, int ld, const int64_t
               const float* loss_and_count, const float* gscale, void* dlogits, void* stream);
 /* next-token selection of model.py:607-621: argmax(softmax(logits/T)) over the LAST dim, first max wins          */
 int mm_argmax_softmax(int dtype, const void* logits, int rows, int V, int ld, float temperature, int64_t* out, void* stream);
+/* the same selection for long rows, the vocabulary cut into chunks over many workgroups (3 short launches instead of one block per
+ * row sweeping 128 258 logits three times); ws: mm_argmax_softmax_ws_bytes(rows, V) bytes, 8-byte aligned                     */
+int mm_argmax_softmax_ws_bytes(int rows, int V);
+int mm_argmax_softmax_split(int dtype, const void* logits, int rows, int V, int ld, float temperature, int64_t* out, void* ws,
+                            void* stream);
 /* generate()'s per-token bookkeeping ON the device (the reference syncs per token: model.py:618-625,637-638): id = finished[b]
  * ? eos : tok[b]; finished[b] |= id == eos; out[b, col] = id; next_ids[b] = id (the next step's embedding lookup).       */
 int mm_decode_select(const int64_t* tok, unsigned char* finished, int64_t eos, int B, int64_t* out, int ld_out, int col,

@@ -575,6 +575,88 @@ __global__ __launch_bounds__(1024) void argmax_softmax_kernel(const T* logits, i
   }
 }
 
+// The same selection for a long row (the decoder's 128 258 logits: one 1024-thread block per row swept them three times in ~80 us
+// per token) with the vocabulary cut into chunks of ARGMAX_CHUNK entries over many workgroups: chunk maxima and exp-sums, then --
+// with the row's max and sum assembled from them in chunk order -- the best rounded probability of each chunk, merged across chunks
+// by ONE 64-bit atomic max on (probability bits << 32 | 0x7FFFFFFF - index): larger probability first, smaller index among equals.
+constexpr int ARGMAX_CHUNK = 4096;
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_part_kernel(const T* logits, int V, int ld, float temperature, float* part, unsigned long long* packed) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, row = blockIdx.y, C = gridDim.x;
+  const T* p = logits + (int64_t)row * ld;
+  auto sc1 = [&](float x) { return to_f32(from_f32<T>(x / temperature)); };
+  const int e0 = c * ARGMAX_CHUNK, e1 = min(V, e0 + ARGMAX_CHUNK);
+  float xv[ARGMAX_CHUNK / 256];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < ARGMAX_CHUNK / 256; ++i) {
+    const int e = e0 + i * 256 + (int)threadIdx.x;
+    xv[i] = e < e1 ? sc1(to_f32(p[e])) : -INFINITY;
+    mx = fmaxf(mx, xv[i]);
+  }
+  mx = block_max_256(mx, red);
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < ARGMAX_CHUNK / 256; ++i) sm += (xv[i] == -INFINITY) ? 0.f : expf(xv[i] - mx);
+  sm = block_sum_256(sm, red);
+  if (threadIdx.x == 0) {
+    part[((int64_t)row * C + c) * 2] = mx;
+    part[((int64_t)row * C + c) * 2 + 1] = sm;
+    if (c == 0) packed[row] = 0ull;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_pick_kernel(const T* logits, int V, int ld, float temperature, const float* part,
+                                                          unsigned long long* packed) {
+  __shared__ float bestv[4];
+  __shared__ int besti[4];
+  const int c = blockIdx.x, row = blockIdx.y, C = gridDim.x;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const T* p = logits + (int64_t)row * ld;
+  auto sc1 = [&](float x) { return to_f32(from_f32<T>(x / temperature)); };
+  float mx = -INFINITY;
+  for (int i = 0; i < C; ++i) mx = fmaxf(mx, part[((int64_t)row * C + i) * 2]);
+  float sm = 0.f;
+  for (int i = 0; i < C; ++i) {                              // chunk order: the same sum in every workgroup
+    const float mi = part[((int64_t)row * C + i) * 2];
+    if (mi != -INFINITY) sm += part[((int64_t)row * C + i) * 2 + 1] * expf(mi - mx);
+  }
+  const int e0 = c * ARGMAX_CHUNK, e1 = min(V, e0 + ARGMAX_CHUNK);
+  float bv = -1.f;
+  int bi = 0x7FFFFFFF;
+#pragma unroll
+  for (int i = 0; i < ARGMAX_CHUNK / 256; ++i) {             // ascending index per thread: `>` keeps the first of equals
+    const int e = e0 + i * 256 + (int)threadIdx.x;
+    if (e < e1) {
+      const float pr = to_f32(from_f32<T>(expf(sc1(to_f32(p[e])) - mx) / sm));
+      if (pr > bv) { bv = pr; bi = e; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (l == 0) { bestv[w] = bv; besti[w] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i)
+      if (bestv[i] > bv || (bestv[i] == bv && besti[i] < bi)) { bv = bestv[i]; bi = besti[i]; }
+    if (bv >= 0.f && bi != 0x7FFFFFFF) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(0x7FFFFFFF - bi);
+      atomicMax(packed + row, key);
+    }
+  }
+}
+
+__global__ void argmax_unpack_kernel(const unsigned long long* packed, int rows, int64_t* out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) out[r] = (int64_t)(0x7FFFFFFF - (unsigned)(packed[r] & 0xFFFFFFFFull));
+}
+
 // ---------------------------------------------------------------- MoE expert fusion (image_modality_moe.py:163-205)
 // X [E, n, L] = the experts' token features (L = P*C), gate [n, E] fp32 = the gating network's softmax weights.
 //   mode 0 (weighted_average, :170-176): out[n, L]    = sum_j  w(n, idx[j]) * X[idx[j], n, :]
@@ -880,6 +962,35 @@ extern "C" int mm_ce_bwd(int dtype, const void* logits, int T, int V, int ld, co
   else
     hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(T), dim3(256), 0, (hipStream_t)stream, (const float*)logits, V, ld, labels, lse,
                        loss_and_count, gscale, (float*)dlogits);
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_argmax_softmax_ws_bytes(int rows, int V) {
+  if (rows <= 0 || V <= 0) return 0;
+  const int64_t C = (V + ARGMAX_CHUNK - 1) / ARGMAX_CHUNK;
+  const int64_t b = (int64_t)rows * 8 + (int64_t)rows * C * 2 * 4;       // packed keys, then (max, sum) per chunk
+  return b > 0x7FFFFFFF ? -1 : (int)b;
+}
+
+extern "C" int mm_argmax_softmax_split(int dtype, const void* logits, int rows, int V, int ld, float temperature, int64_t* out, void* ws,
+                                       void* stream) {
+  if (!logits || !out || !ws || rows < 0 || V <= 0 || ld < V || !(temperature > 0.f)) return MM_ERR_ARG;
+  if (((uintptr_t)ws) & 7) return MM_ERR_ALIGN;
+  if (rows == 0) return MM_OK;
+  const int C = (V + ARGMAX_CHUNK - 1) / ARGMAX_CHUNK;
+  unsigned long long* packed = (unsigned long long*)ws;
+  float* part = (float*)(packed + rows);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)C, (unsigned)rows), block(256);
+  if (dtype == MM_BF16) {
+    hipLaunchKernelGGL(argmax_part_kernel<bf16>, grid, block, 0, s, (const bf16*)logits, V, ld, temperature, part, packed);
+    hipLaunchKernelGGL(argmax_pick_kernel<bf16>, grid, block, 0, s, (const bf16*)logits, V, ld, temperature, (const float*)part, packed);
+  } else {
+    hipLaunchKernelGGL(argmax_part_kernel<float>, grid, block, 0, s, (const float*)logits, V, ld, temperature, part, packed);
+    hipLaunchKernelGGL(argmax_pick_kernel<float>, grid, block, 0, s, (const float*)logits, V, ld, temperature, (const float*)part, packed);
+  }
+  hipLaunchKernelGGL(argmax_unpack_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, (const unsigned long long*)packed, rows, out);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

@@ -595,6 +595,11 @@ def ce_bwd(logits2d, V, labels, lse, loss_and_count, gscale, dlogits2d):
 def argmax_softmax(logits2d, V, temperature):
     rows = logits2d.shape[0]
     out = torch.empty(rows, dtype=torch.int64, device=logits2d.device)
+    if V >= 16384 and _os.environ.get("MM_ARGMAX_SPLIT", "1") != "0":      # long rows: the vocabulary over many workgroups
+        nb = _lib.lib().mm_argmax_softmax_ws_bytes(rows, V)
+        ws = torch.empty((nb + 7) // 8, dtype=torch.int64, device=logits2d.device)
+        call("mm_argmax_softmax_split", dt(logits2d), _p(logits2d), rows, V, logits2d.stride(0), float(temperature), _p(out), _p(ws), _stream())
+        return out
     call("mm_argmax_softmax", dt(logits2d), _p(logits2d), rows, V, logits2d.stride(0), float(temperature), _p(out), _stream())
     return out
 

@@ -965,3 +965,26 @@ def test_rows_select_both_directions(K, dtype):
     want = torch.zeros(B * S, H, dtype=dtype, device="cuda")
     want[keep.cuda()] = dy
     assert torch.equal(dx, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("V", [128258, 16384, 40000])
+def test_argmax_softmax_long_rows(K, dtype, V, monkeypatch):
+    """mm_argmax_softmax_split (the vocabulary in 4096-entry chunks over many workgroups, one 64-bit atomic max per chunk) picks what
+    torch.argmax(torch.softmax(logits / T)) picks in the logits dtype and what the one-block-per-row kernel picks -- including ties
+    between equal rounded probabilities (first index wins) and a padded row stride."""
+    rows, ld = 5, (V + 63) // 64 * 64
+    logits = rnd((rows, V), dtype, 91, 2.0)
+    logits[1, 7] = logits[1].max() + 1.0                      # a clear winner early in the row
+    logits[2, V - 3] = logits[2].max() + 1.0                  # ... and in the ragged tail of the last chunk
+    logits[3, 5000] = logits[3, 9000] = logits[3].max() + 2.0   # an exact tie across two chunks: the first index wins
+    buf = torch.full((rows, ld), float("nan"), dtype=dtype, device="cuda")
+    buf[:, :V] = logits.cuda()
+    for T_ in (0.1, 1.0):
+        want = torch.argmax(torch.softmax(logits / T_, dim=-1), dim=-1)
+        got = K.argmax_softmax(buf[:, :V], V, T_).cpu()
+        monkeypatch.setenv("MM_ARGMAX_SPLIT", "0")
+        one = K.argmax_softmax(buf[:, :V], V, T_).cpu()
+        monkeypatch.setenv("MM_ARGMAX_SPLIT", "1")
+        assert torch.equal(got, want) and torch.equal(got, one), (T_, got, want, one)
+    assert int(got[1]) == 7 and int(got[2]) == V - 3 and int(got[3]) == 5000
