@@ -355,6 +355,8 @@ int mm_fill_zero(void* p, int64_t bytes, void* stream);
  * on such streams so that the small kernels of the modality tower they overlap always find free CUs.  mm_debug_cu_probe: where
  * the workgroups of a launch on `stream` ran (XCC_ID and HW_ID registers), for tools/cumask_probe.py.                            */
 int mm_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream);
+int mm_stream_priority_range(int* least, int* greatest);
+int mm_stream_create_priority(int priority, void** stream);
 int mm_stream_destroy(void* stream);
 int mm_device_cu_count(void);
 int mm_debug_cu_probe(void* out_u32, int n_wg, int threads, int64_t spin_ticks, void* stream);

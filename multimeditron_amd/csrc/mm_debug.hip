@@ -66,6 +66,19 @@ extern "C" int mm_stream_create_cu_mask(const unsigned* mask, int nwords, void**
   *stream = (void*)s;
   return MM_OK;
 }
+// a stream of the given HIP priority (hipDeviceGetStreamPriorityRange: numerically LOWER = served first; `least` is the lowest
+// priority the device offers): the Trainer can put a saturating side burst BELOW the default stream's small kernels
+extern "C" int mm_stream_priority_range(int* least, int* greatest) {
+  if (!least || !greatest) return MM_ERR_ARG;
+  return hipDeviceGetStreamPriorityRange(least, greatest) == hipSuccess ? MM_OK : MM_ERR_UNSUPPORTED;
+}
+extern "C" int mm_stream_create_priority(int priority, void** stream) {
+  if (!stream) return MM_ERR_ARG;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) { (void)hipGetLastError(); return MM_ERR_UNSUPPORTED; }
+  *stream = (void*)s;
+  return MM_OK;
+}
 extern "C" int mm_stream_destroy(void* stream) {
   if (!stream) return MM_ERR_ARG;
   return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? MM_OK : MM_ERR_ARG;

@@ -719,6 +719,25 @@ def masked_stream(n_enabled: int, scheme: str = "hash", tag: str = ""):
     return st
 
 
+def priority_stream(priority: int, tag: str = ""):
+    """A torch stream object over a HIP stream of the given priority (lower number = served first; cached per process)."""
+    import ctypes
+    key = (torch.cuda.current_device(), "prio", int(priority), tag)
+    st = _masked_streams.get(key)
+    if st is None:
+        out = ctypes.c_void_p()
+        call("mm_stream_create_priority", int(priority), ctypes.cast(ctypes.pointer(out), ctypes.c_void_p))
+        st = _masked_streams[key] = torch.cuda.ExternalStream(out.value)
+    return st
+
+
+def stream_priority_range():
+    import ctypes
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    call("mm_stream_priority_range", ctypes.cast(ctypes.pointer(lo), ctypes.c_void_p), ctypes.cast(ctypes.pointer(hi), ctypes.c_void_p))
+    return lo.value, hi.value
+
+
 def cu_probe(n_wg, threads, spin_ticks, stream=None):
     """-> int64 [n_wg, 2] (XCC id, HW_ID register) of a spinning launch on `stream` (default: the current stream)."""
     out = torch.zeros((n_wg, 2), dtype=torch.int32, device="cuda")

@@ -128,6 +128,9 @@ class MultimodalTrainer:
         n = int(os.environ.get(env, str(_SIDE_CUS_DEFAULT.get(env, 0))))
         if n > 0 and torch.cuda.is_available():
             return K.masked_stream(n, tag=env)
+        lowprio = os.environ.get(env.replace("_CUS", "_PRIO"))          # MM_ADAMW_PRIO / MM_DEFER_PRIO: a HIP stream priority (experiment)
+        if lowprio is not None and torch.cuda.is_available():
+            return K.priority_stream(int(lowprio), tag=env)
         return torch.cuda.Stream(priority=priority)
 
     def _setup_wgrad_deferral(self):
