@@ -196,7 +196,7 @@ def _frozen_towers(experts, pixels, tower):
                         tower(e, ex, static_px)
             cur.wait_stream(warm)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _no_gc(), torch.cuda.graph(graph):
                 main = torch.cuda.current_stream()
                 res = []
                 for e, ex in enumerate(experts):                          # fork: every tower on its own branch of the graph
@@ -213,6 +213,22 @@ def _frozen_towers(experts, pixels, tower):
     static_px.copy_(pixels)
     graph.replay()
     return [o.clone() for o in res]
+
+
+class _no_gc:
+    """No automatic garbage collection while a hipGraph is being captured: a collection that happens to run mid-capture can destroy
+    an OLDER graph (an earlier model's towers) -- releasing a graph's memory pool is not a capturable operation and aborts the
+    process.  (torch.cuda.graph collects once on entry; this keeps the interpreter from collecting again before the capture ends.)"""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
 
 
 def _graphable(experts):
@@ -244,7 +260,7 @@ class _TowerGraphs:
                 tower(e, ex, self.static_px)
         cur.wait_stream(warm)
         self.fwd = torch.cuda.CUDAGraph()
-        with torch.enable_grad(), torch.cuda.graph(self.fwd):
+        with _no_gc(), torch.enable_grad(), torch.cuda.graph(self.fwd):
             main = torch.cuda.current_stream()
             self.res = []
             for e, ex in enumerate(experts):
@@ -316,7 +332,7 @@ class _TowerGraphs:
             try:
                 self._flags(fresh)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool):
+                with _no_gc(), torch.cuda.graph(g, pool=self.pool):
                     self._run_autograd()
             finally:
                 F_.set_grad_ready_hook(hook)
