@@ -505,6 +505,10 @@ def main():
             if fps is not None:
                 roof["whole_step_achieved"] = round(step_tf, 2)
                 roof["whole_step_frac"] = round(step_tf / PEAK_BF16_TFLOPS, 4)
+                if fps_exec != fps:      # the same step priced with the flops of HF's form of it (every row through lm_head and the last MLP)
+                    hf_tf = value / world * fps / 1e12
+                    roof["whole_step_achieved_hf_form_flops"] = round(hf_tf, 2)
+                    roof["whole_step_frac_hf_form_flops"] = round(hf_tf / PEAK_BF16_TFLOPS, 4)
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             del trainer, model, batch, feed
