@@ -293,8 +293,12 @@ class _TowerGraphs:
 
     def forward(self, pixels):
         for m in self.mods:                                                  # parameter-read hooks (the Trainer's per-block wait for
-            for hook in list(m._forward_pre_hooks.values()):                 # the overlapped optimiser): the replay calls no module
-                hook(m, ())
+            kw = getattr(m, "_forward_pre_hooks_with_kwargs", {})            # the overlapped optimiser): the replay calls no module
+            for hid, hook in list(m._forward_pre_hooks.items()):
+                if hid in kw:
+                    hook(m, (), {})
+                else:
+                    hook(m, ())
         self.static_px.copy_(pixels)
         self.fwd.replay()
         return [o.detach().clone() for o in self.res]
