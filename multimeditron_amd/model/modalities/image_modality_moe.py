@@ -248,7 +248,6 @@ class _TowerGraphs:
         from ... import functional as F_
         self.experts = experts
         self.params = [p for ex in experts for p in ex.parameters() if p.requires_grad]
-        self.mods = [m for ex in experts for m in ex.modules() if m._forward_pre_hooks]
         dev = pixels.device
         self.streams = [_expert_stream(dev, e) for e in range(len(experts))]
         self.static_px = pixels.detach().clone()
@@ -292,7 +291,8 @@ class _TowerGraphs:
             main.wait_stream(st)
 
     def forward(self, pixels):
-        for m in self.mods:                                                  # parameter-read hooks (the Trainer's per-block wait for
+        mods = [m for ex in self.experts for m in ex.modules() if m._forward_pre_hooks]      # looked up per call: a Trainer may come later
+        for m in mods:                                                       # parameter-read hooks (the Trainer's per-block wait for
             kw = getattr(m, "_forward_pre_hooks_with_kwargs", {})            # the overlapped optimiser): the replay calls no module
             for hid, hook in list(m._forward_pre_hooks.items()):
                 if hid in kw:
