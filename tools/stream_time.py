@@ -44,7 +44,20 @@ for q, xs in by_q.items():
         agg[k][1] += min(e, w1) - max(s, w0)
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"   {k:72s} {c:5d}  {t / 1e6:8.2f} ms  avg {t / c / 1e3:8.1f} us")
-    after = [x for x in by_q[main_q] if x[0] >= w1][:3]
+    tail = [x for x in by_q[main_q] if x[0] >= w1]
+    stop = next((i for i, x in enumerate(tail) if "sumsq" in x[2] or "adamw" in x[2]), len(tail))
+    if stop:
+        t_end = tail[stop - 1][1]
+        agg2 = collections.defaultdict(lambda: [0, 0])
+        for s2, e2, n2, _, g2 in tail[:stop]:
+            k2 = (n2[n2.find("::") + 2:] if n2.startswith("void (anonymous") or n2.startswith("(anonymous") else n2)[:58] + f" g={g2}"
+            agg2[k2][0] += 1
+            agg2[k2][1] += e2 - s2
+        print(f"   compute stream AFTER the window, up to the gradient-norm sweep / AdamW: {stop} launches over {(t_end - w1) / 1e6:.2f} ms "
+              f"(busy {sum(v[1] for v in agg2.values()) / 1e6:.2f} ms)")
+        for k2, (c2, t2) in sorted(agg2.items(), key=lambda kv: -kv[1][1])[:10]:
+            print(f"      {k2:72s} {c2:5d}  {t2 / 1e6:8.2f} ms  avg {t2 / c2 / 1e3:8.1f} us")
+    after = tail[:3]
     before = [x for x in by_q[main_q] if x[1] <= w0][-2:]
     print("   compute stream just before:", [(n[:40], round((e - s) / 1e3, 1)) for s, e, n, *_ in before])
     print("   compute stream just after: ", [(n[:40], round((s - w1) / 1e3, 1), round((e - s) / 1e3, 1)) for s, e, n, *_ in after])
