@@ -41,14 +41,14 @@ if rows:
 block("generate(): prefill + decode, B = 4, S = 2048, 8B (`tools/decode_bench.py`)", f"other_{pre}/decode.log", tail=3,
       note="Weights streamed per token: 16.06 GB (8.03 B bf16 parameters of the decoder + lm_head); KV cache read per token: 1.07 GB.")
 block("the decode layer's kernels one by one (`tools/gemv_bench.py 4 16`: 16 layers' weights in rotation, event-timed back-to-back launches)",
-      "r3_exp1[4-9]/gemv.txt")
+      f"other_{pre}/gemv.txt")
 block("GPU-side durations of the same kernels (`rocprofv3 --kernel-trace --stats` over tools/gemv_bench.py)", "r3_exp16/prof/kernel_stats.txt")
 block("D = 128 attention forward / backward (`tools/attn_bench.py --quick`)", f"other_{pre}/attn_quick.log")
 block("row-wise kernels alone (`tools/rowwise_bench.py`)", f"other_{pre}/rowwise.log")
-block("MoE image modality, 4 x ViT-L/14 experts on 4 images (`tools/moe_bench.py 4 4`)", "r3_exp13/moe_bench.txt")
+block("MoE image modality, 4 x ViT-L/14 experts on 4 images (`tools/moe_bench.py 4 4`)", f"other_{pre}/moe_bench.txt")
 block("the headline's image modality alone (`tools/vit_bench.py 4` + its rocprofv3 kernel table)", "r3_vit/alone.txt")
 block("... per kernel", "r3_vit/kernel_stats.txt", tail=22)
-block("per-stream composition of one training step and the two overlap windows (`tools/stream_time.py`)", "r3_trace1/stream_time.txt")
+block("per-stream composition of one training step and the two overlap windows (`tools/stream_time.py`)", "r3_trace2/stream_time.txt")
 for tag, title in (("r3_exp7", "AdamW split master / RoPE epilogue"), ("r3_exp9", "sum of squares in the wgrad epilogue (EK = 5)"),
                    ("r3_exp11", "labelled rows: final norm + lm_head + loss"), ("r3_exp15", "labelled rows incl. the last layer's o_proj + MLP"),
                    ("r3_exp12", "CU-masked side streams (rejected)"), ("r3_exp18", "low-priority side streams (rejected)")):
