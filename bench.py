@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--mode", default="FULL", choices=["FULL", "ALIGNMENT", "END2END", "LM_ONLY"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-all-rows", action="store_true", help="skip the extra timing of the step in HF's all-rows form (MM_LOSS_ROWS=0)")
     ap.add_argument("--padded", action="store_true", help="right-padded batch, lengths U[S/2, S] (SURVEY 8d: the key-mask path); "
                                                           "not the headline configuration")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal on CPU/gloo: no model, no kernels, no measurement")
@@ -481,10 +482,33 @@ def main():
     # the instrumented extra step issues the same gradient-exchange collectives as any other step: EVERY rank runs it
     # (rank 0 alone would leave its all-reduces unmatched and hang); only rank 0 reports
     r = measure_gemm_roofline(trainer, batch) if not args.no_roofline else None
+    # the same step in HF's form (every row through the last layer's MLP, the final norm, lm_head and the loss), timed beside the
+    # headline so that both numbers come from one process on one box: every rank runs it (collectives), rank 0 reports
+    all_rows = None
+    if trainer.loss_rows_only and not args.no_all_rows:
+        trainer.loss_rows_only = False
+        k2 = max(3, args.steps // 2)
+        for _ in range(2):
+            trainer.training_step(next(feed))
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            trainer.training_step(next(feed))
+        sync()
+        e2 = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([e2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t)
+        trainer.loss_rows_only = True
+        all_rows = {"ms_per_step": round(1e3 * e2 / k2, 3), "value": round(world * B * k2 / e2, 4), "steps": k2}
     if rank == 0:
         if fps is not None:
             step_tf = value / world * fps_exec / 1e12
             out["config"]["flops_per_sample_fwd_bwd"] = fps_exec
+            if all_rows is not None:
+                out["config"]["all_rows_form"] = dict(all_rows, note="the same step with MM_LOSS_ROWS=0 (logits of every row, as HF computes "
+                                                      "them), timed after the headline in this process")
             if rows is not None:
                 out["config"]["loss_rows"] = (f"last layer's o_proj + MLP, final norm, lm_head and cross-entropy on the {rows.n} of {rows.total} rows whose shifted label is "
                                               f"not -100 (same loss and gradients; MM_LOSS_ROWS=0 computes every row as HF does: "
