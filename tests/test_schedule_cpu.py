@@ -72,3 +72,17 @@ def test_loss_rows_follow_hf_shift_and_ignore_rule():
                                              ignore_index=-100)
     rows = torch.nn.functional.cross_entropy(logits[idx.long()], lab)
     assert abs(float(full) - float(rows)) < 1e-6
+
+
+def test_cu_mask_spreads_the_disabled_cus_evenly():
+    """kernels.cu_mask_words ("hash"): whichever way the driver numbers CUs -- round-robin over the 8 XCDs (what tools/cumask_probe.py
+    found on MI355X) or XCD by XCD -- every XCD loses the same number of CUs."""
+    from multimeditron_amd.kernels import cu_mask_words
+    for enabled in (248, 240, 224, 192, 128):
+        words = cu_mask_words(enabled, 256, "hash")
+        bits = [(words[i // 32] >> (i % 32)) & 1 for i in range(256)]
+        assert sum(bits) == enabled
+        per_rr = [sum(bits[i] for i in range(256) if i % 8 == x) for x in range(8)]
+        per_blk = [sum(bits[32 * x:32 * x + 32]) for x in range(8)]
+        assert per_rr == [enabled // 8] * 8, (enabled, per_rr)
+        assert max(per_blk) - min(per_blk) <= 4, (enabled, per_blk)      # contiguous numbering: roughly even (the probe found round-robin)
