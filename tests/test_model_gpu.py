@@ -255,3 +255,43 @@ def test_reference_written_checkpoint_reproduces_reference_logits(golden_dir):
     assert float((got - ref).norm() / ref.norm()) < 1e-4
     assert torch.equal(got.argmax(-1), ref.argmax(-1))
     assert abs(float(o.loss) - float(v["loss"])) < 1e-4 * max(1.0, abs(float(v["loss"])))
+
+
+@pytest.mark.parametrize("Hq,Hkv,bias,H", [(4, 1, False, 256), (2, 1, True, 384), (8, 1, False, 512), (4, 2, True, 1024)])
+def test_fused_decode_chain_at_head_width_128(Hq, Hkv, bias, H, monkeypatch):
+    """The decode step at the head width the fused chain is built for (D = 128; the golden models are narrower and take the generic
+    decode step): every layer as 6 launches -- RMSNorm + q|k|v + RoPE + cache append, attention slices (scores on MFMA for <= 4
+    query heads per kv head) + merge, o_proj + residual, RMSNorm + gate|up + SwiGLU, down + residual -- and lm_head with the final
+    norm in its prologue, against (a) the same steps on the separate launches (MM_DECODE_FUSED=0): logits BIT-identical, step after
+    step; (b) the prefill kernels on the whole sequence: within bf16 noise."""
+    from multimeditron_amd.model.llm import CausalLM, LLMConfig
+    from multimeditron_amd.nn import FlatParams
+    torch.manual_seed(0)
+    cfg = LLMConfig(model_type="qwen2" if bias else "llama", hidden_size=H, intermediate_size=2 * H + 64, num_hidden_layers=2,
+                    num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=128, vocab_size=1003, attention_bias=bias)
+    m = CausalLM(cfg, dtype=torch.bfloat16, device="cuda")
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            p.copy_((torch.randn(p.shape, device="cuda") * (0.3 if p.dim() == 1 else 0.05) + (1.0 if "norm" in k else 0.0)).to(p.dtype))
+    FlatParams([(k, p, "llm") for k, p in m.named_parameters()], "cuda", torch.bfloat16)
+    m.eval()
+    B, S, n_new = 3, 37, 5
+    ids = torch.randint(0, cfg.vocab_size, (B, S + n_new), device="cuda")
+    logits = {}
+    with torch.no_grad():
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MM_DECODE_FUSED", mode)
+            out = m(input_ids=ids[:, :S], use_cache=True, max_new_tokens=n_new + 1)
+            cache, steps = out.past_key_values, []
+            for i in range(n_new):
+                pos = torch.full((B, 1), S + i, device="cuda", dtype=torch.long)
+                o = m(input_ids=ids[:, S + i:S + i + 1], past_key_values=cache, use_cache=True, position_ids=pos)
+                assert all(layer.can_decode_step_fused(torch.empty(B, H, dtype=torch.bfloat16, device="cuda"), B, 1, cache[0]) == (mode == "1")
+                           for layer in m.model.layers)
+                steps.append(o.logits[:, -1].float().clone())
+            logits[mode] = steps
+        full = m(input_ids=ids).logits.float()
+    for i, (a, b) in enumerate(zip(logits["1"], logits["0"])):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+        ref = full[:, S + i]
+        assert float((a - ref).norm() / ref.norm()) < 3e-2, i
