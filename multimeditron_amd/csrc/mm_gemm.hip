@@ -1215,19 +1215,31 @@ __device__ __forceinline__ void rmsnorm_rows_to_lds(const bf16* x, int ldx, cons
         xv[r][c] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, (t < 256 && e < H) ? (unsigned)e * 2u : 0xFFFFFFFFu, 0, 0));
       }
     }
+    // the R rows' sums of squares meet in ONE pair of barriers (block_sum_256's order per row: lanes of a wave, then waves 0..3)
+    float ssr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int e = (c * 256 + t) * 8;
+        if (t < 256 && e < H && r0 + r < nrows) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float f = (float)xv[r][c][i]; ss += f * f; }
+        }
+      }
+      ssr[r] = wave_sum(ss);
+    }
+    __syncthreads();
+    if ((t & 63) == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) red[(t >> 6) * 4 + r] = ssr[r];
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (r0 + r < nrows) {                                // uniform
-        float ss = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int e = (c * 256 + t) * 8;
-          if (t < 256 && e < H) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const float f = (float)xv[r][c][i]; ss += f * f; }
-          }
-        }
-        ss = block_sum_256(ss, red);
+        const float ss = red[0 * 4 + r] + red[1 * 4 + r] + red[2 * 4 + r] + red[3 * 4 + r];
         const float rs = rsqrtf(ss / (float)H + eps);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -1252,7 +1264,7 @@ template <int MODE, bool NORM, bool NT>
 __global__ __launch_bounds__(512, 4) void gemv_stream_kernel(SkinnyArgs g, int nblocks) {      // 4 waves per SIMD (2 workgroups per CU): <= 128 VGPRs
   extern __shared__ __attribute__((aligned(16))) char xs[];          // x, M rows of K bf16 (normalised when NORM)
   __shared__ float red[2][8][4][64];
-  __shared__ float nred[8];
+  __shared__ float nred[8 * 4];                                       // [wave][row of the norm batch]
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = l & 15, kc = l >> 4;
   // the lane's row of W in row block `blk` (as MFMA A-operand row `row`) as a byte offset, or out of range
