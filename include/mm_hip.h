@@ -168,6 +168,9 @@ int mm_layernorm_bwd(int dtype, const void* dy, const void* x, const void* w, co
 int mm_norm_bwd_blocks(int M);
 /* out[H] (+)= sum_b partial[b,H]  (f32 partials -> param-dtype gradient)                                    */
 int mm_reduce_partials(int dtype, const float* partial, int nblk, int H, void* out, int accumulate, void* stream);
+/* the same for two (partials, output) pairs in one launch: LayerNorm's dw and db */
+int mm_reduce_partials2(int dtype, const float* partial0, const float* partial1, int nblk, int H, void* out0, void* out1, int accumulate0,
+                        int accumulate1, void* stream);
 
 /* ---- RoPE: HF:llama:113-160 (rotate_half form) --------------------------------------------------------
  * cos/sin tables [T, D/2] f32 from position_ids and inv_freq (HF:llama:113-127; llama3 scaling is applied by

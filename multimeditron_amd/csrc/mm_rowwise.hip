@@ -221,9 +221,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
 // lanes, every lane's 16-byte loads of its rows all in flight at once, then a fixed-order tree through LDS (deterministic).
 // The old shape (64 columns x 4 row lanes, 64 workgroups, 4-byte loads: 128 dependent rounds per thread) took 44 us on the
 // decoder's 512 x 4096 partials (8.4 MB, L2/MALL resident); this one is bounded by one round of L2 latency.
+// blockIdx.y selects one of two (partials, output) pairs: LayerNorm's dw and db leave backward in ONE launch (each launch of the
+// ViT's backward chain costs ~90 us while the deferred weight-gradient GEMMs hold the CUs, whatever its own work is)
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* p, int nblk, int H, T* out, int accumulate) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* p, int nblk, int H, T* out, int accumulate, const float* p1 = nullptr,
+                                                              T* out1 = nullptr, int accumulate1 = 0) {
   __shared__ f32x4 red[64][4];
+  if (blockIdx.y == 1) { p = p1; out = out1; accumulate = accumulate1; }
   const int c4 = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int h = blockIdx.x * 16 + c4 * 4;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
@@ -798,6 +802,20 @@ extern "C" int mm_layernorm_bwd(int dtype, const void* dy, const void* x, const 
     if (H % 4) return MM_ERR_ALIGN;
     DISPATCH_CH(float, norm_ch<float>(H), hipLaunchKernelGGL((layernorm_bwd_kernel<float, CH>), dim3(nb), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)w, mean, rstd, M, H, (float*)dx, dwp, dbp, (const float*)dres));
   }
+  MM_CHECK_LAUNCH();
+  return MM_OK;
+}
+
+extern "C" int mm_reduce_partials2(int dtype, const float* partial0, const float* partial1, int nblk, int H, void* out0, void* out1, int accumulate0,
+                                   int accumulate1, void* stream) {
+  if (!partial0 || !partial1 || !out0 || !out1 || nblk < 0 || H <= 0) return MM_ERR_ARG;
+  if ((H & 3) || !mm_aligned16(partial0) || !mm_aligned16(partial1)) return MM_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((H + 15) / 16, 2), block(256);
+  if (dtype == MM_BF16)
+    hipLaunchKernelGGL(reduce_partials_kernel<bf16>, grid, block, 0, s, partial0, nblk, H, (bf16*)out0, accumulate0, partial1, (bf16*)out1, accumulate1);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel<float>, grid, block, 0, s, partial0, nblk, H, (float*)out0, accumulate0, partial1, (float*)out1, accumulate1);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

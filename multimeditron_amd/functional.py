@@ -291,6 +291,12 @@ class LayerNormFn(torch.autograd.Function):
         if dy is None:
             return dres, None, None, None, None
         dx, dwp, dbp = K.layernorm_bwd(dy.contiguous(), x, w.data, mean, rstd, dres.contiguous() if dres is not None else None)
+        if w.requires_grad and b.requires_grad:          # dw and db in one launch
+            (gw, aw), (gb, ab) = grad_target(w), grad_target(b)
+            K.reduce_partials2(dwp, dbp, gw, gb, aw, ab)
+            _ready(w)
+            _ready(b)
+            return dx, None, None, None, None
         if w.requires_grad:
             g, acc = grad_target(w)
             K.reduce_partials(dwp, g, acc)

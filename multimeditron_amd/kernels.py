@@ -421,6 +421,12 @@ def layernorm_bwd(dy2d, x2d, w, mean, rstd, dres=None):
     return dx, dwp, dbp
 
 
+def reduce_partials2(partial0, partial1, out0, out1, accumulate0, accumulate1):
+    assert partial0.shape == partial1.shape and out0.dtype == out1.dtype
+    call("mm_reduce_partials2", dt(out0), _p(partial0), _p(partial1), partial0.shape[0], partial0.shape[1], _p(out0), _p(out1), int(accumulate0),
+         int(accumulate1), _stream())
+
+
 def reduce_partials(partial, out, accumulate):
     call("mm_reduce_partials", dt(out), _p(partial), partial.shape[0], partial.shape[1], _p(out), int(accumulate), _stream())
     return out
