@@ -48,10 +48,11 @@ block("row-wise kernels alone (`tools/rowwise_bench.py`)", f"other_{pre}/rowwise
 block("MoE image modality, 4 x ViT-L/14 experts on 4 images (`tools/moe_bench.py 4 4`)", f"other_{pre}/moe_bench.txt")
 block("the headline's image modality alone (`tools/vit_bench.py 4` + its rocprofv3 kernel table)", "r3_vit/alone.txt")
 block("... per kernel", "r3_vit/kernel_stats.txt", tail=22)
-block("per-stream composition of one training step and the two overlap windows (`tools/stream_time.py`)", "r3_trace2/stream_time.txt")
+block("per-stream composition of one training step and the two overlap windows (`tools/stream_time.py`)", "r3_exp23/trace/stream_time.txt")
 for tag, title in (("r3_exp7", "AdamW split master / RoPE epilogue"), ("r3_exp9", "sum of squares in the wgrad epilogue (EK = 5)"),
                    ("r3_exp11", "labelled rows: final norm + lm_head + loss"), ("r3_exp15", "labelled rows incl. the last layer's o_proj + MLP"),
-                   ("r3_exp12", "CU-masked side streams (rejected)"), ("r3_exp18", "low-priority side streams (rejected)")):
+                   ("r3_exp12", "CU-masked side streams (rejected)"), ("r3_exp18", "low-priority side streams (rejected)"),
+                   ("r3_exp22", "plain NT / NN decoder GEMMs through the vendor library (opt-in MM_GEMM_LIB=1)")):
     block(f"step A/B, same process (`tools/step_ab.py`): {title}", f"{tag}/step_ab.txt", tail=8)
 block("CU masks: where the workgroups of a masked stream run (`tools/cumask_probe.py`)", "r3_cumask.log", tail=11)
 block("weights just read by another kernel vs cold (`tools/mall_probe.py`)", "r3_mall.log", tail=4)
