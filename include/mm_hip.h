@@ -353,13 +353,6 @@ int mm_fill_zero(void* p, int64_t bytes, void* stream);
  * tr_read: img = 4096 bf16 copied to LDS; lane l reads at byte address addr[l]; out[l*4+j] = its j-th element.
  * mfma: shape 32 -> v_mfma_f32_32x32x16_bf16 (out 64x16 f32), 16 -> v_mfma_f32_16x16x32_bf16 (out 64x4 f32);
  *       a/b = 64 lanes x 8 bf16 fragments.                                                                         */
-/* Plain bf16 GEMMs through the vendor library (hipBLASLt, bound at run time: no link-time dependency).  The task's rules reserve
- * the library for PLAIN GEMMs; every fused epilogue and the weight gradients stay on mm_gemm's hand-written kernels.
- * mm_gemm_lib: C[M,N] = A B^T (MM_GEMM_NT) or A B (MM_GEMM_NN) (+ residual when not NULL), row-major, fp32 accumulation;
- * ws / ws_bytes = caller's workspace.  MM_ERR_UNSUPPORTED when the library (or a kernel for the shape) is absent: keep mm_gemm. */
-int mm_gemm_lib_available(void);
-int mm_gemm_lib(int dtype, int layout, int M, int N, int K, const void* A, int lda, const void* B, int ldb, const void* residual,
-                int ldr, void* C, int ldc, void* ws, int64_t ws_bytes, void* stream);
 /* Streams restricted to a subset of the CUs (no reference counterpart: the reference leaves kernel placement to PyTorch).  `mask`:
  * bit i of word i / 32 enables CU i (hipExtStreamCreateWithCUMask).  The Trainer runs AdamW and the deferred weight-gradient GEMMs
  * on such streams so that the small kernels of the modality tower they overlap always find free CUs.  mm_debug_cu_probe: where

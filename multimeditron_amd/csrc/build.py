@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmmhip.so")
-SOURCES = ["mm_gemm.hip", "mm_attn.hip", "mm_rowwise.hip", "mm_embed.hip", "mm_optim.hip", "mm_debug.hip", "mm_comm.hip", "mm_image.hip", "mm_xattn.hip", "mm_blaslt.hip"]
+SOURCES = ["mm_gemm.hip", "mm_attn.hip", "mm_rowwise.hip", "mm_embed.hip", "mm_optim.hip", "mm_debug.hip", "mm_comm.hip", "mm_image.hip", "mm_xattn.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

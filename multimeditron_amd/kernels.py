@@ -60,18 +60,6 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
         assert residual.stride(-1) == 1
     if accumulate:
         epi |= EPI_ACCUMULATE
-    if (_gemm_lib_on() and layout in (GEMM_NT, GEMM_NN) and a.dtype == torch.bfloat16 and bias is None and act == 0 and not accumulate
-            and sumsq is None and M >= 2048 and N >= 1024 and K >= 1024 and a.is_cuda):
-        # a PLAIN product (+ residual) of the decoder's size: the vendor library where it is bound (csrc/mm_blaslt.hip; same bits)
-        ws = _gemm_lib_ws.get(a.device)
-        if ws is None:
-            ws = _gemm_lib_ws[a.device] = torch.empty(64 << 20, dtype=torch.uint8, device=a.device)
-        rc = _lib.lib().mm_gemm_lib(dt(a), layout, M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(residual),
-                                    residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), _p(ws), ws.numel(), _stream())
-        if rc == 0:
-            return out
-        if rc != -3:                                  # -3 = MM_ERR_UNSUPPORTED: no library / no kernel for the shape -> mm_gemm below
-            raise _lib.MMHipError(f"mm_gemm_lib failed: {rc}")
     if sumsq is not None:
         assert bias is None and residual is None and act == 0
         call("mm_gemm_sumsq", dt(a), layout, M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), epi, _p(sumsq),
@@ -80,17 +68,6 @@ def gemm(layout: int, a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, 
     call("mm_gemm", dt(a), layout, M, N, K, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), _p(bias),
          _p(residual), residual.stride(0) if residual is not None else 0, epi, _stream())
     return out
-
-
-_gemm_lib_ws = {}
-
-
-def _gemm_lib_on():        # MM_GEMM_LIB=1: plain NT / NN products of the decoder's size go to the vendor library (default: see DESIGN.md)
-    import os
-    return os.environ.get("MM_GEMM_LIB", _GEMM_LIB_DEFAULT) == "1"
-
-
-_GEMM_LIB_DEFAULT = "0"
 
 
 def linear_fwd(x2d, w, bias=None, residual=None, act=0, ldc_pad=False):
