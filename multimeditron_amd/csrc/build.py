@@ -27,7 +27,10 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(HERE, "mm_common.h"), os.path.join(PKG, "..", "include", "mm_hip.h")]
+    gen, inc = os.path.join(HERE, "gen_gemm_w4.py"), os.path.join(HERE, "mm_gemm_w4.inc")
+    if force or _stale(inc, [gen]):                     # the 4-wave GEMM's main loop (asm text) is generated
+        subprocess.run([sys.executable, gen], check=True, stdout=subprocess.DEVNULL)
+    headers = [os.path.join(HERE, "mm_common.h"), os.path.join(PKG, "..", "include", "mm_hip.h"), inc]
     jobs = []
     for src in SOURCES:
         s = os.path.join(HERE, src)

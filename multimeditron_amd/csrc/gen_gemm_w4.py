@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled main loop of gemm_bf16_w4_kernel (mm_gemm.hip): writes mm_gemm_w4.inc.
+
+    python multimeditron_amd/csrc/gen_gemm_w4.py          (build.py runs it when the .inc is older than this file)
+
+The kernel is the 256x256x64 bf16 GEMM tile on FOUR waves (2 x 2), one wave per SIMD with the SIMD's whole 512-entry register
+file: a wave owns 128 x 128 of the tile = 8 x 8 accumulator tiles of v_mfma_f32_16x16x32_bf16 in a[0:255], and two fragment
+sets of 16 operand fragments (one per 32-deep half of the K-step) in v[128:255].  Per K-step a wave issues 128 MFMAs and reads
+32 KB of fragments (8 A + 8 B fragments per half); the 8-wave form of the same tile (128 x 64 per wave) reads 24 KB per wave =
+192 KB per workgroup against 128 KB here, which is what made that form LDS-port-bound.  hipcc cannot hold
+this shape (round 3: ~170 spilt registers, 810-960 TFLOP/s), so register allocation and instruction order are fixed HERE: the
+whole K loop of one output tile is ONE asm statement with literal registers, everything else (tile map, descriptors, epilogues)
+stays HIP C++.
+
+Stream structure (one barrier per K-step; s = K-step, stage(s) = s & 1 of the 2 x 64 KB LDS ring, DMA = the wave's 8 + 8
+1-KiB `buffer_load_dwordx4 ... lds` pieces of an A | B stage):
+
+    phase A(s):  64 MFMAs on fragment set 0 (k = 0..31 of step s)    | ds_reads of set 1 (k = 32..63 of step s) from stage(s)
+    P(s):        s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier            -> every wave's DMA(s+1) has landed, every wave is done
+                                                                         reading stage(s)
+    phase B(s):  64 MFMAs on fragment set 1                          | ds_reads of set 0 of step s+1 from stage(s+1)
+                                                                      | DMA(s+2) into stage(s), descriptor / ring bookkeeping
+
+so a DMA has one whole K-step (128 MFMAs) to land and every fragment is requested at least ~20 MFMAs before its first use.  The
+waits in front of the MFMAs are counted lgkmcnt(N), computed below from the issue order (LDS reads return in order).
+K-steps of successive tiles form one stream: the DMA of K-steps nk, nk+1 go to the NEXT tile (its descriptors are inputs), so
+the ring never drains between tiles; the accumulators are zeroed by the first K-step's MFMAs taking C = 0.
+
+Register map (literal, all in the clobber list): a[0:255] acc[i][j] = a[(8i+j)*4 ..]; v[128:159] A set 0, v[160:191] B set 0,
+v[192:223] A set 1, v[224:255] B set 1; v[100:107] / v[108:115] per-piece DMA offsets of A / B; v[116:123] / v[92:99] LDS read
+addresses of A / B; v[124:127] scratch; s[64:67] / s[68:71] running descriptors of A / B; s78 K-step of the next DMA inside its
+tile; s84 loop count; s85 saved M0; s86 LDS byte address of this wave's first piece in the stage being refilled; s87-s89 scratch.
+"""
+import os
+import sys
+
+ACC = lambda i, j: (i * 8 + j) * 4
+FR = {("A", 0): 128, ("B", 0): 160, ("A", 1): 192, ("B", 1): 224}
+V_RD = {"A": 116, "B": 92}
+V_VOFF = {"A": 100, "B": 108}
+V_TMP = 124
+S_DESC = {"A": 64, "B": 68}
+S_KD, S_LOOP, S_M0, S_DST, S_T0, S_SB = 78, 84, 85, 86, 87, 88
+TILE_OFF = {"A": 0, "B": 32768}
+# set-0 fragments are requested >= 20 MFMAs (320+ cycles) before the K-step that uses them starts: ONE lgkmcnt(0) at the top of
+# phase A never stalls in steady state and replaces ~20 counted waits per K-step (False = the counted form, kept for experiments)
+COARSE_WAITS = True
+STAGE = 0x10000
+
+
+class Variant:
+    def __init__(self, name, a_kc, b_kc):
+        self.name, self.kc = name, {"A": a_kc, "B": b_kc}
+
+    # ---- LDS fragment reads: returns the instructions of fragment (X, ks, x)
+    def frag_reads(self, X, ks, x):
+        dst = FR[(X, ks)] + 4 * x
+        if self.kc[X]:      # [row][64 k] image, 16-byte chunks XOR-swizzled by row: one ds_read_b128, lane base per ks, +2048 per 16 rows
+            return [f"ds_read_b128 v[{dst}:{dst + 3}], v{V_RD[X] + ks} offset:{x * 2048}"]
+        # [k][256 x] image rotated by k: the lane's row part and its rotated column depend on x -> one address register per x;
+        # k + 32 (ks) and k + 4 (second half of the fragment) are constant byte offsets
+        return [f"ds_read_b64_tr_b16 v[{dst}:{dst + 1}], v{V_RD[X] + x} offset:{ks * 16384}",
+                f"ds_read_b64_tr_b16 v[{dst + 2}:{dst + 3}], v{V_RD[X] + x} offset:{ks * 16384 + 2048}"]
+
+    def read_order(self, ks):      # the first MFMA row needs A[0] and B[0..7]
+        return [("A", ks, 0)] + [("B", ks, j) for j in range(8)] + [("A", ks, i) for i in range(1, 8)]
+
+    def rd_regs(self, X):
+        return [V_RD[X], V_RD[X] + 1] if self.kc[X] else [V_RD[X] + x for x in range(8)]
+
+
+class Emitter:
+    """Program-order instruction list with automatic counted lgkmcnt waits in front of the MFMAs."""
+
+    def __init__(self):
+        self.out = []
+        self.lds_issued = 0            # LDS operations issued so far
+        self.frag_last = {}            # fragment -> index (1-based count) of its last read
+        self.done_upto = 0             # every LDS operation with index <= done_upto is known to have returned
+
+    def raw(self, s):
+        self.out.append(s)
+
+    def lds(self, frag, insts):
+        for s in insts:
+            self.out.append(s)
+            self.lds_issued += 1
+        self.frag_last[frag] = self.lds_issued
+
+    def need(self, frags):
+        last = max(self.frag_last[f] for f in frags)
+        if last > self.done_upto:
+            n = self.lds_issued - last
+            if n > 15:
+                n = 15                 # 4-bit field: waiting for more than needed is safe
+            self.out.append(f"s_waitcnt lgkmcnt({n})")
+            self.done_upto = self.lds_issued - n
+
+    def lgkm_wait(self):
+        self.out.append("s_waitcnt lgkmcnt(0)")
+        self.done_upto = self.lds_issued
+
+    def full_wait(self):
+        self.out.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        self.done_upto = self.lds_issued
+
+
+def mfma(i, j, ks, first):
+    a, b, c = FR[("A", ks)] + 4 * i, FR[("B", ks)] + 4 * j, ACC(i, j)
+    src = "0" if first else f"a[{c}:{c + 3}]"
+    return f"v_mfma_f32_16x16x32_bf16 a[{c}:{c + 3}], v[{b}:{b + 3}], v[{a}:{a + 3}], {src}"
+
+
+def spread(n, lo, hi):
+    """gap index of each of n items spread evenly over gaps lo .. hi-1"""
+    return [lo + (k * (hi - lo)) // n for k in range(n)]
+
+
+def desc_advance(X, step):
+    d = S_DESC[X]
+    return [f"s_add_u32 s{d}, s{d}, {step}", f"s_addc_u32 s{d + 1}, s{d + 1}, 0",
+            f"s_sub_u32 s{d + 2}, s{d + 2}, {step}", f"s_cselect_b32 s{d + 2}, 0, s{d + 2}"]      # num_records saturates at 0
+
+
+def gen_variant(v):
+    e = Emitter()
+    kcA, kcB = v.kc["A"], v.kc["B"]
+    stepA = "128" if kcA else f"s{S_SB + 1}"
+    stepB = "128" if kcB else f"s{S_SB}"
+    # ------------------------------------------------------------------ entry
+    e.raw(f"s_mov_b32 s{S_M0}, m0")
+    e.raw("s_waitcnt lgkmcnt(0)")
+    for X, p in (("A", "a"), ("B", "b")):
+        d = S_DESC[X]
+        e.raw(f"s_mov_b32 s{d}, %[{p}0]")
+        e.raw(f"s_mov_b32 s{d + 1}, %[{p}1]")
+        e.raw(f"s_mov_b32 s{d + 2}, %[{p}2]")
+        e.raw(f"s_mov_b32 s{d + 3}, 0x20000")
+    if not kcB:
+        e.raw(f"s_lshl_b32 s{S_SB}, %[tb0], 2")          # K-step of a K-strided B = 64 rows = 4 x the 16-row piece stride
+    if not kcA:
+        e.raw(f"s_lshl_b32 s{S_SB + 1}, %[ta], 2")
+    # the tile's K-steps 0 and 1 are already in flight: the running descriptors start at K-step 2
+    for X, st in (("A", stepA), ("B", stepB)):
+        for _ in range(2):
+            for s in desc_advance(X, st):
+                e.raw(s)
+    e.raw(f"s_mov_b32 s{S_KD}, 2")
+    e.raw(f"s_sub_u32 s{S_LOOP}, %[nk], 1")
+    e.raw(f"s_mov_b32 s{S_DST}, %[dst]")
+    # per-piece DMA offsets: piece i of a wave = piece 0 + wave-uniform strides
+    for X, p in (("A", "a"), ("B", "b")):
+        vo = V_VOFF[X]
+        if v.kc[X]:          # bits 0, 1, 2 of i -> strides t0, t1, t2 (plain rows: 32, 64, 128 rows; the gathers permute them)
+            t0, t1, t2 = (f"%[t{p}0]", f"%[t{p}1]", f"%[t{p}2]") if X == "B" else ("%[ta]", f"s{S_T0}", f"s{S_T0 + 2}")
+            e.raw(f"v_mov_b32 v{vo}, %[voff{p}0]")
+            if X == "A":
+                e.raw(f"s_lshl_b32 s{S_T0}, %[ta], 1")
+                e.raw(f"s_lshl_b32 s{S_T0 + 2}, %[ta], 2")
+            e.raw(f"v_add_u32 v{vo + 1}, {t0}, v{vo}")
+            for k in range(2):
+                e.raw(f"v_add_u32 v{vo + 2 + k}, {t1}, v{vo + k}")
+            for k in range(4):
+                e.raw(f"v_add_u32 v{vo + 4 + k}, {t2}, v{vo + k}")
+        else:                # two lane patterns (even / odd pieces), 16 rows between pieces of equal parity
+            e.raw(f"v_mov_b32 v{vo}, %[voff{p}0]")
+            e.raw(f"v_mov_b32 v{vo + 1}, %[voff{p}1]")
+            for k in range(2, 8):
+                e.raw(f"v_add_u32 v{vo + k}, %[t{p}0], v{vo + k - 2}")
+    # LDS read addresses
+    for X, p in (("A", "a"), ("B", "b")):
+        if v.kc[X]:
+            e.raw(f"v_mov_b32 v{V_RD[X]}, %[rd{p}0]")
+            e.raw(f"v_mov_b32 v{V_RD[X] + 1}, %[rd{p}1]")
+        else:                # address of fragment x = row part + ((column part + 32 x) mod 512)
+            for x in range(8):
+                e.raw(f"v_add_u32 v{V_TMP}, {32 * x}, %[rd{p}1]")
+                e.raw(f"v_and_b32 v{V_TMP}, 511, v{V_TMP}")
+                e.raw(f"v_add_u32 v{V_RD[X] + x}, %[rd{p}0], v{V_TMP}")
+    # fragment set 0 of K-step 0 (the same reads, in the same order, as phase B issues for the following K-step)
+    for f in v.read_order(0):
+        e.lds(f, v.frag_reads(*f))
+
+    # ------------------------------------------------------------------ one K-step
+    def kstep(first):
+        # ---- phase A
+        reads = v.read_order(1)
+        insts = [(f, s) for f in reads for s in [v.frag_reads(*f)]]
+        gaps = spread(len(insts), 0, 40)
+        aux = {g: [] for g in range(64)}
+        for (f, s), g in zip(insts, gaps):
+            aux[g].append(("lds", f, s))
+        toggles = [f"v_xor_b32 v{r}, {STAGE}, v{r}" for X in "AB" for r in v.rd_regs(X)]      # after the last read of stage(s)
+        for s, g in zip(toggles, spread(len(toggles), 44, 62)):
+            aux[g].append(("raw", s))
+        m = 0
+        if COARSE_WAITS:
+            e.lgkm_wait()
+        for i in range(8):
+            for j in range(8):
+                e.need([("A", 0, i), ("B", 0, j)])
+                e.raw(mfma(i, j, 0, first))
+                for a in aux[m]:
+                    if a[0] == "lds":
+                        e.lds(a[1], a[2])
+                    else:
+                        e.raw(a[1])
+                m += 1
+        # ---- P
+        e.full_wait()
+        e.raw("s_barrier")
+        # ---- phase B
+        reads = v.read_order(0)
+        insts = [(f, s) for f in reads for s in [v.frag_reads(*f)]]
+        aux = {g: [] for g in range(64)}
+        for (f, s), g in zip(insts, spread(len(insts), 0, 44)):
+            aux[g].append(("lds", f, s))
+        k = 0
+        for X in "AB":
+            for i in range(8):
+                aux[2 * k].append(("raw", f"s_add_u32 m0, s{S_DST}, {TILE_OFF[X] + i * 4096}"))
+                aux[2 * k + 1].append(("raw", f"buffer_load_dwordx4 v{V_VOFF[X] + i}, s[{S_DESC[X]}:{S_DESC[X] + 3}], 0 offen lds"))
+                k += 1
+        # bookkeeping behind the last DMA: advance the descriptors one K-step; at the end of the tile's K range switch to the
+        # next tile's descriptors (their K-step 0); flip the stage the next DMA refills
+        book = desc_advance("A", stepA) + desc_advance("B", stepB)
+        book += [f"s_add_u32 s{S_KD}, s{S_KD}, 1", f"s_cmp_eq_u32 s{S_KD}, %[nk]", f"s_cmov_b32 s{S_KD}, 0"]
+        for X, p in (("A", "na"), ("B", "nb")):
+            for q in range(3):
+                book.append(f"s_cmov_b32 s{S_DESC[X] + q}, %[{p}{q}]")
+        book.append(f"s_xor_b32 s{S_DST}, s{S_DST}, {STAGE}")
+        g0, n0 = 33, 0
+        for s in book:          # SCC chains (add / addc, sub / cselect, cmp / cmov) stay in order: two instructions per gap
+            aux[g0].append(("raw", s))
+            n0 += 1
+            if n0 == 2:
+                g0, n0 = g0 + 1, 0
+        m = 0
+        for i in range(8):
+            for j in range(8):
+                e.need([("A", 1, i), ("B", 1, j)])
+                e.raw(mfma(i, j, 1, False))
+                for a in aux[m]:
+                    if a[0] == "lds":
+                        e.lds(a[1], a[2])
+                    else:
+                        e.raw(a[1])
+                m += 1
+
+    kstep(True)                                          # K-step 0: C = 0
+    e.raw("L_w4_loop_%=:")
+    kstep(False)
+    e.raw(f"s_sub_u32 s{S_LOOP}, s{S_LOOP}, 1")
+    e.raw(f"s_cmp_lg_u32 s{S_LOOP}, 0")
+    e.raw("s_cbranch_scc1 L_w4_loop_%=")
+    # ------------------------------------------------------------------ exit
+    e.raw("s_waitcnt lgkmcnt(0)")                        # the last phase B's fragment reads land in v[128:191]
+    e.raw("s_nop 7")                                     # MFMA results -> v_accvgpr_read (the epilogue's statements)
+    e.raw("s_nop 7")
+    e.raw("s_nop 7")
+    e.raw(f"s_mov_b32 m0, s{S_M0}")
+    return e.out
+
+
+def operands(v):
+    """(name, constraint) of the asm inputs, in the order the kernel passes them"""
+    ops = []
+    for X, p in (("A", "a"), ("B", "b")):
+        ops += [(f"voff{p}0", "v")] + ([] if v.kc[X] else [(f"voff{p}1", "v")])
+        ops += [(f"rd{p}0", "v"), (f"rd{p}1", "v")]
+    for p in ("a", "b", "na", "nb"):
+        ops += [(f"{p}{q}", "s") for q in range(3)]
+    ops += [("ta", "s")]
+    ops += [("tb0", "s")] + ([("tb1", "s"), ("tb2", "s")] if v.kc["B"] else [])
+    ops += [("nk", "s"), ("dst", "s")]
+    return ops
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = ["// GENERATED by gen_gemm_w4.py -- do not edit.  Main loop of gemm_bf16_w4_kernel (see the generator's header).", ""]
+    clob = [f"v{r}" for r in range(92, 256)] + [f"a{r}" for r in range(256)] + [f"s{r}" for r in range(64, 90)] + ["memory", "scc"]
+    out.append("#define MM_W4_CLOBBERS " + ", ".join(f'"{c}"' for c in clob))
+    out.append("")
+    for v in (Variant("NT", True, True), Variant("NN", True, False)):
+        body = gen_variant(v)
+        nm = sum(1 for s in body if s.startswith("v_mfma"))
+        out.append(f"// {v.name}: {len(body)} instructions, {nm} MFMAs (3 K-step bodies' worth: peeled first step + loop)")
+        out.append(f"#define MM_W4_ASM_{v.name} \\")
+        for s in body:
+            out.append(f'  "{s}\\n\\t" \\')
+        out.append('  ""')
+        ops = operands(v)
+        out.append(f"#define MM_W4_INPUTS_{v.name}(" + ", ".join("p_" + n for n, _ in ops) + ") \\")
+        out.append("  " + ", ".join(f'[{n}] "{c}"(p_{n})' for n, c in ops))
+        out.append("")
+    # accumulator read-out for the epilogue: chunk c = columns 64c .. 64c+63 of the wave's 128 (acc[i][4c + jj])
+    for c in range(2):
+        out.append(f"__device__ __forceinline__ void w4_read_acc_c{c}(f32x4 (&acc)[8][4]) {{")
+        for i in range(8):
+            for jj in range(4):
+                n = ACC(i, 4 * c + jj)
+                out.append("  { float t0, t1, t2, t3; asm volatile(\"v_accvgpr_read_b32 %0, a" + str(n) + "\\n\\tv_accvgpr_read_b32 %1, a" + str(n + 1) +
+                           "\\n\\tv_accvgpr_read_b32 %2, a" + str(n + 2) + "\\n\\tv_accvgpr_read_b32 %3, a" + str(n + 3) +
+                           "\" : \"=v\"(t0), \"=v\"(t1), \"=v\"(t2), \"=v\"(t3)); acc[" + str(i) + "][" + str(jj) + "] = f32x4{t0, t1, t2, t3}; }")
+        out.append("}")
+        out.append("")
+    path = os.path.join(here, "mm_gemm_w4.inc")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    print(path)
+
+
+if __name__ == "__main__":
+    main()

@@ -1085,6 +1085,139 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The same 256x256x64 tile on FOUR waves (2 x 2), one wave per SIMD, 128 x 128 of the tile per wave (round 4).
+// The 8-wave form above moves 8 x 24 KB of fragment reads + 64 KB of LDS-DMA writes through the LDS port per K-step: as many port
+// clocks as the K-step's MFMAs take; four waves of 128 x 128 read 4 x 32 KB.  That shape needs the whole
+// 512-entry register file of a SIMD (256 accumulators + two sets of 16 fragments) and an instruction order hipcc does not
+// produce (round 3: ~170 spilt registers), so the K loop of one output tile is ONE asm statement with literal registers,
+// generated by gen_gemm_w4.py (stream structure, register map and hazards: that file's header).  Everything around it is the code
+// above: the LDS images and DMA source swizzles (dma_offsets), the persistent XCD-aware tile map, the buffer descriptors with the
+// hardware range check, and the epilogues, which see a wave as two of the 8-wave form's 128 x 64 wave tiles (columns 64 c ..).
+// Same products in the same K order as the 8-wave kernel: bit-identical output.  A is K-contiguous (NT, NN); K % 64 == 0 and
+// K >= 192 (the host sends anything else to the 8-wave kernel).
+// ------------------------------------------------------------------------------------------------------
+#include "mm_gemm_w4.inc"
+
+__device__ __forceinline__ unsigned w4_sgpr(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+
+template <bool B_KC, int EK>
+__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bf16* A = (const bf16*)g.A;
+  const bf16* B = (const bf16*)g.B;
+  const int l = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int nk = g.K / G_BK;
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  if (lds0 != 0) __builtin_trap();                  // the ring's stage bit (0x10000) is flipped by XOR on absolute LDS addresses
+  const int total = g.nbm * g.nbn;
+  int tile = blockIdx.x;
+  if (tile >= total) return;
+  const int swi = (EK == 3) ? g.swi_I : (EK == 4 ? -1 : 0);       // B-row gather of the fused gate|up / RoPE tiles (gather_row)
+  const int nstep = swi > 0 ? 128 : 256;
+  int pm, pn;
+  block_to_tile(tile, g.nbm, g.nbn, pm, pn);
+  int m0 = pm * 256, n0 = pn * nstep;
+  SRsrc ra = tile_rsrc<true>(A, g.lda, m0, g.M, g.K);
+  SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
+  unsigned offa[8], offb[8];
+  dma_offsets<true, 256, 4>(offa, g.lda);
+  dma_offsets<B_KC, 256, 4>(offb, g.ldb, swi);
+  const unsigned ldb2 = (unsigned)g.ldb * 2u;
+  // K-steps 0 and 1 of the first tile; from here on every tile's asm statement issues K-steps 2.. and the next tile's 0 and 1
+  dma_tile_inv<256, 4>(lds0, ra, offa, 0u);
+  dma_tile_inv<256, 4>(lds0 + 32768u, rb, offb, 0u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  dma_tile_inv<256, 4>(lds0 + 65536u, ra, offa, 128u);
+  dma_tile_inv<256, 4>(lds0 + 65536u + 32768u, rb, offb, B_KC ? 128u : 64u * ldb2);
+  // lane parts of the fragment addresses (frag_load2's formulas with the wave's first row block; + 2048 per 16 rows in the asm)
+  const unsigned voffa0 = offa[0], voffb0 = offb[0], voffb1 = offb[1];
+  const int lr = l & 15, lg = l >> 4;
+  const unsigned rda_lo = (unsigned)((wm * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
+  const unsigned rda_hi = (unsigned)((wm * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
+  unsigned rdb_lo, rdb_hi;
+  if constexpr (B_KC) {
+    rdb_lo = 32768u + (unsigned)((wn * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
+    rdb_hi = 32768u + (unsigned)((wn * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
+  } else {                                          // K-strided image: row part, and the rotated 32-byte column slot of fragment 0
+    const int q = lr >> 2, p = lr & 3, k = 8 * lg + q;
+    rdb_lo = 32768u + (unsigned)(k * 512 + p * 8);
+    rdb_hi = (unsigned)(((wn * 8 + ks_swz(k)) & 15) * 32);
+  }
+  // wave-uniform strides between a wave's DMA pieces (piece i = 8 rows at local row 8 w + 32 i; bits 0, 1, 2 of i)
+  const unsigned ta = w4_sgpr(64u * (unsigned)g.lda);
+  unsigned tb0, tb1 = 0, tb2 = 0;
+  if constexpr (B_KC) {
+    if (swi > 0) { tb0 = (unsigned)swi * ldb2; tb1 = 32u * ldb2; tb2 = 64u * ldb2; }          // swiglu_row: bit 0 -> + I rows
+    else if (swi < 0) { tb0 = 64u * ldb2; tb1 = 32u * ldb2; tb2 = 128u * ldb2; }               // rope_row
+    else { tb0 = 32u * ldb2; tb1 = 64u * ldb2; tb2 = 128u * ldb2; }
+  } else {
+    tb0 = 16u * ldb2;                               // 16 k-rows between pieces of equal parity
+  }
+  tb0 = w4_sgpr(tb0); tb1 = w4_sgpr(tb1); tb2 = w4_sgpr(tb2);
+  const unsigned nk_s = w4_sgpr((unsigned)nk);
+  unsigned sidx = 0;                                // K-steps streamed so far (ring position)
+  while (tile < total) {
+    const int next = tile + gridDim.x;
+    int nm0 = 0, nn0 = 0;
+    unsigned na0 = 0, na1 = 0, na2 = 0, nb0 = 0, nb1 = 0, nb2 = 0;     // no next tile: empty descriptors (every DMA lane out of range)
+    if (next < total) {
+      int qm, qn;
+      block_to_tile(next, g.nbm, g.nbn, qm, qn);
+      nm0 = qm * 256;
+      nn0 = qn * nstep;
+      const SRsrc nra = tile_rsrc<true>(A, g.lda, nm0, g.M, g.K), nrb = tile_rsrc<B_KC>(B, g.ldb, nn0, g.N, g.K);
+      na0 = nra.w0; na1 = nra.w1; na2 = nra.w2; nb0 = nrb.w0; nb1 = nrb.w1; nb2 = nrb.w2;
+    }
+    na0 = w4_sgpr(na0); na1 = w4_sgpr(na1); na2 = w4_sgpr(na2); nb0 = w4_sgpr(nb0); nb1 = w4_sgpr(nb1); nb2 = w4_sgpr(nb2);
+    const unsigned st = (sidx & 1u) * 65536u;
+    const unsigned a0 = ra.w0, a1 = ra.w1, a2 = ra.w2, b0 = rb.w0, b1 = rb.w1, b2 = rb.w2;
+    const unsigned rda0 = rda_lo + st, rda1 = rda_hi + st, rdb0 = rdb_lo + st;
+    const unsigned dst = w4_sgpr(st + (unsigned)w * 1024u);
+    if constexpr (B_KC) {
+      const unsigned rdb1 = rdb_hi + st;
+      asm volatile(MM_W4_ASM_NT
+                   :
+                   : MM_W4_INPUTS_NT(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1,
+                                     tb2, nk_s, dst)
+                   : MM_W4_CLOBBERS);
+    } else {
+      const unsigned rdb1 = rdb_hi;
+      asm volatile(MM_W4_ASM_NN
+                   :
+                   : MM_W4_INPUTS_NN(voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0,
+                                     nk_s, dst)
+                   : MM_W4_CLOBBERS);
+    }
+    sidx += (unsigned)nk;
+    // epilogue: the accumulators leave a[0:255] in two halves of 64 columns = one wave tile of the 8-wave form each
+    const int mw = m0 + wm * 128;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x4 acc[8][4];
+      if (c == 0) w4_read_acc_c0(acc);
+      else w4_read_acc_c1(acc);
+      const int vw = 2 * wn + c;                    // the 8-wave form's wave column
+      if constexpr (EK == 4) gemm_epilogue_rope<8, 4>(g, acc, mw, n0, vw);
+      else if constexpr (EK == 3) gemm_epilogue_swiglu<8, 4>(g, acc, mw, n0 + vw * 32);
+      else if constexpr (EK == 2) gemm_epilogue_ek2<8, 4>(g, acc, mw, n0 + vw * 64);
+      else if constexpr (EK == 0) gemm_epilogue_ek0<8, 4>(g, acc, mw, n0 + vw * 64);
+      else gemm_epilogue_plain<8, 4, false, true>(g, acc, mw, n0 + vw * 64);
+    }
+    tile = next;
+    m0 = nm0;
+    n0 = nn0;
+    if (next < total) {
+      ra = tile_rsrc<true>(A, g.lda, m0, g.M, g.K);
+      rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (empty) DMAs issued for a tile that does not exist
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Skinny NT GEMM for KV-cache decode (reference model.py:595-602: one new token per sequence, M = batch <= 16).
 // C[M,N] = A[M,K] . W[N,K]^T is a stream over W (16 GB of bf16 weights per token for the 8B decoder): HBM-bound, so the
 // kernel is laid out for bytes in flight, not for MFMA occupancy.  One workgroup = 16 rows of W, its 8 waves split K;
@@ -1583,6 +1716,7 @@ static int small_variant(int M, int N, int K) {
 }
 static int g_opt_epi_pipe = 1;      // pipelined, branch-free epilogue of the plain / SwiGLU-backward LDS-DMA kernels
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
+static int g_opt_w4 = 1;            // NT / NN 256x256 tiles on the 4-wave hand-scheduled kernel (gemm_bf16_w4_kernel); 0 = the 8-wave kernel (A/B)
 
 extern "C" int mm_attn_set_issue_waves(int v);
 int mm_attn_option(const char* name, int value);
@@ -1603,6 +1737,7 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_epi_pipe")) { g_opt_epi_pipe = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
+  if (!strcmp(name, "gemm_w4")) { g_opt_w4 = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 6) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -1618,6 +1753,7 @@ extern "C" int mm_get_option(const char* name, int* value) {
   if (!strcmp(name, "gemm_persist")) { *value = g_opt_persist; return MM_OK; }
   if (!strcmp(name, "gemm_epi_pipe")) { *value = g_opt_epi_pipe; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { *value = g_opt_issue_waves; return MM_OK; }
+  if (!strcmp(name, "gemm_w4")) { *value = g_opt_w4; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { *value = g_opt_kernel; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -1899,6 +2035,26 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       static const int ncu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; return n; }();
       // persistent: one resident workgroup per CU walks the tiles; otherwise one tile each
       int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
+      // NT / NN 256x256 tiles: the 4-wave kernel (A K-contiguous, whole K-steps, the epilogue kinds it instantiates)
+      const bool acts = (epilogue & (MM_EPI_GELU_ERF | MM_EPI_QUICK_GELU | MM_EPI_GELU_TANH)) != 0;
+      if (g_opt_w4 && variant == 2 && layout != MM_GEMM_TN && (K & 63) == 0 && K >= 192 && !g.ss && !acts) {
+        const int64_t nb4 = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
+        dim3 grid4((unsigned)nb4), block4(256);
+#define MM_LAUNCH_W4(BKC, EK)                                                                                            \
+  do {                                                                                                                   \
+    auto kfn = gemm_bf16_w4_kernel<BKC, EK>;                                                                             \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    hipLaunchKernelGGL(kfn, grid4, block4, lds, s, g);                                                                   \
+  } while (0)
+        if (g.rope_cols) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, 4); }
+        else if (g.swi_I) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, 3); }
+        else if (epilogue & MM_EPI_SWIGLU_BWD) { if (layout != MM_GEMM_NN) return MM_ERR_ARG; MM_LAUNCH_W4(false, 2); }
+        else if (layout == MM_GEMM_NT) MM_LAUNCH_W4(true, 0);
+        else MM_LAUNCH_W4(false, 0);
+#undef MM_LAUNCH_W4
+        MM_CHECK_LAUNCH();
+        return MM_OK;
+      }
       if (g_opt_persist && g_opt_tail && variant == 2 && !g.swi_I && !g.rope_cols) {       // wave quantisation: see the kernel
         const int64_t rem = nwg % ncu;
         if (rem > 0 && 2 * rem <= ncu) {

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""The 4-wave hand-scheduled GEMM (gemm_bf16_w4_kernel, mm_set_option gemm_w4 = 1) against the 8-wave kernel (gemm_w4 = 0) on the
+GPU box: BIT identity on plain / residual / accumulate / fused SwiGLU / SwiGLU-backward / RoPE shapes with ragged M and N, several
+repetitions (a missing wait shows as rare wrong tiles), then interleaved timing on the step's NT / NN shapes.
+
+    python tools/w4_check.py [--quick] [--time-only] [--check-only]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimeditron_amd import kernels as K
+from multimeditron_amd._lib import lib
+
+NT, NN = 0, 1
+
+
+def set_opt(name, v):
+    assert lib().mm_set_option(name.encode(), v) == 0
+
+
+def rnd(g, *s):
+    return (torch.rand(*s, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def both(fn):
+    out = []
+    for mode in (0, 1):
+        set_opt("gemm_w4", mode)
+        out.append(fn())
+    set_opt("gemm_w4", 1)
+    torch.cuda.synchronize()
+    return out
+
+
+def same(a, b):
+    if isinstance(a, (tuple, list)):
+        return all(same(x, y) for x, y in zip(a, b))
+    return torch.equal(a, b)
+
+
+def check():
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bad = 0
+    set_opt("gemm_kernel", 3)             # every case on the 256x256 tile (small problems would pick a smaller one)
+    cases = [(NT, 8192, 4096, 4096), (NT, 5112, 6144, 4096), (NT, 1000, 1544, 320), (NT, 2049, 4104, 1024), (NT, 8192, 4096, 14336),
+             (NN, 8192, 4096, 6144), (NN, 5112, 4096, 4096), (NN, 1111, 1032, 448), (NN, 4096, 14336, 4096), (NN, 300, 520, 192)]
+    for lay, M, N, Kd in cases:
+        a = rnd(g, M, Kd)
+        b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, pad64(N))[:, :N]
+        res = rnd(g, M, N)
+        for kind in ("plain", "residual", "accumulate"):
+            def run():
+                c = torch.zeros(M, pad64(N), device="cuda", dtype=torch.bfloat16)[:, :N]
+                if kind == "accumulate":
+                    c.copy_(res)
+                K.gemm(lay, a, b, M, N, Kd, out=c, residual=res if kind == "residual" else None, accumulate=kind == "accumulate")
+                return c.clone()
+            for rep in range(3):
+                o0, o1 = both(run)
+                ok = same(o0, o1)
+                if not ok:
+                    d = (o0.float() - o1.float()).abs()
+                    rows = (d.amax(1) > 0).nonzero().flatten()
+                    cols = (d.amax(0) > 0).nonzero().flatten()
+                    print(f"  MISMATCH max {float(d.max()):.4g} at rows {rows[:4].tolist()}..{rows[-1:].tolist()} ({rows.numel()}) cols {cols[:4].tolist()}..{cols[-1:].tolist()} ({cols.numel()})")
+                    bad += 1
+                    break
+            ref = a.float() @ (b.float().t() if lay == NT else b.float())
+            if kind != "plain":
+                ref = ref + res.float()
+            err = float((o1.float() - ref).norm() / ref.norm())
+            print(f"{'NT' if lay == NT else 'NN'} M={M} N={N} K={Kd} {kind}: {'bit-identical' if ok else 'DIFFERENT'}  rel-L2 vs fp32 {err:.2e}", flush=True)
+    # fused gate|up + SwiGLU (NT), SwiGLU backward on the down_proj dgrad (NN), q|k|v + RoPE (NT)
+    for M, I, H in ((8192, 14336, 4096), (1000, 1024, 512), (5112, 2048, 4096)):
+        x, wgu = rnd(g, M, H), rnd(g, 2 * I, H) * 0.05
+        o0, o1 = both(lambda: tuple(t.clone() for t in K.gemm_swiglu_fwd(x, wgu, I)))
+        ok = same(o0, o1)
+        bad += not ok
+        print(f"swiglu_fwd M={M} I={I} K={H}: {'bit-identical' if ok else 'DIFFERENT'}", flush=True)
+        dy, wd, gu = rnd(g, M, H), rnd(g, H, I) * 0.05, o0[0]
+        o0, o1 = both(lambda: K.gemm_swiglu_bwd(dy, wd, gu, I).clone())
+        ok = same(o0, o1)
+        bad += not ok
+        print(f"swiglu_bwd M={M} I={I} H={H}: {'bit-identical' if ok else 'DIFFERENT'}", flush=True)
+    for M, Hq, Hkv, H, bias in ((8192, 32, 8, 4096, False), (1000, 4, 2, 512, True), (5112, 28, 4, 3584, True)):
+        N = (Hq + 2 * Hkv) * 128
+        x, w = rnd(g, M, H), rnd(g, N, H) * 0.05
+        bv = rnd(g, N) if bias else None
+        cos = torch.rand(M, 64, device="cuda", generator=g)
+        sin = torch.rand(M, 64, device="cuda", generator=g)
+        o0, o1 = both(lambda: K.gemm_rope_fwd(x, w, bv, (Hq + Hkv) * 128, 128, cos, sin).clone())
+        ok = same(o0, o1)
+        bad += not ok
+        print(f"rope_fwd M={M} N={N} K={H} bias={bias}: {'bit-identical' if ok else 'DIFFERENT'}", flush=True)
+    set_opt("gemm_kernel", 0)
+    print("CHECK", "FAILED" if bad else "OK", flush=True)
+    return bad
+
+
+def timing(quick):
+    T = 8192
+    shapes = [(NT, T, 6144, 4096), (NT, T, 4096, 4096), (NT, T, 28672, 4096), (NT, T, 4096, 14336), (NT, T, 128258, 4096),
+              (NN, T, 4096, 6144), (NN, T, 4096, 4096), (NN, T, 4096, 28672), (NN, T, 14336, 4096)]
+    if quick:
+        shapes = shapes[:2] + shapes[5:7]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    tot = {0: 0.0, 1: 0.0}
+    for lay, M, N, Kd in shapes:
+        a = rnd(g, M, Kd)
+        b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, N)
+        c = torch.empty(M, pad64(N), device="cuda", dtype=torch.bfloat16)[:, :N]
+        res = {0: [], 1: []}
+        for rnd_ in range(6):
+            for mode in (0, 1):
+                set_opt("gemm_w4", mode)
+                K.gemm(lay, a, b, M, N, Kd, out=c)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    K.gemm(lay, a, b, M, N, Kd, out=c)
+                e1.record()
+                torch.cuda.synchronize()
+                res[mode].append(e0.elapsed_time(e1) / 3)
+        fl = 2.0 * M * N * Kd
+        med = {m: sorted(v)[len(v) // 2] for m, v in res.items()}
+        for m in med:
+            tot[m] += med[m]
+        print(f"{'NT' if lay == NT else 'NN'} M={M:6d} N={N:6d} K={Kd:6d}  8-wave {fl / med[0] / 1e9:7.1f} TF/s   4-wave {fl / med[1] / 1e9:7.1f} TF/s", flush=True)
+    set_opt("gemm_w4", 1)
+    print("TOTAL ms", tot, flush=True)
+
+
+if __name__ == "__main__":
+    rc = 0
+    if "--time-only" not in sys.argv:
+        rc = check()
+    if "--check-only" not in sys.argv:
+        timing("--quick" in sys.argv)
+    sys.exit(1 if rc else 0)
