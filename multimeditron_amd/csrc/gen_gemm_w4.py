@@ -42,10 +42,44 @@ V_TMP = 124
 S_DESC = {"A": 64, "B": 68}
 S_KD, S_LOOP, S_M0, S_DST, S_T0, S_SB = 78, 84, 85, 86, 87, 88
 TILE_OFF = {"A": 0, "B": 32768}
-# set-0 fragments are requested >= 20 MFMAs (320+ cycles) before the K-step that uses them starts: ONE lgkmcnt(0) at the top of
-# phase A never stalls in steady state and replaces ~20 counted waits per K-step (False = the counted form, kept for experiments)
-COARSE_WAITS = True
+# `coarse` waits: set-0 fragments are requested >= 20 MFMAs (320+ cycles) before the K-step that uses them starts, so ONE
+# lgkmcnt(0) at the top of phase A replaces ~20 counted waits per K-step (coarse=False = the counted form)
 STAGE = 0x10000
+
+
+class Sched:
+    """Where the non-MFMA instructions of a K-step sit: gap g = behind the g-th MFMA of a 64-MFMA phase."""
+
+    def __init__(self, sid, ra=(0, 40), tog=(44, 62), rb=(0, 44), dma0=1, dma_stride=2, book0=50, coarse=True,
+                 no_dma=False, no_reads=False, no_sync=False, no_vmwait=False, no_barrier=False, oob_dma=False, diag=False,
+                 wave_shift=0, read_shift=0, stamps=False):
+        self.sid, self.ra, self.tog, self.rb, self.dma0, self.dma_stride, self.book0 = sid, ra, tog, rb, dma0, dma_stride, book0
+        self.coarse, self.no_dma, self.no_reads, self.no_sync, self.diag = coarse, no_dma, no_reads, no_sync, diag
+        self.no_vmwait, self.no_barrier, self.oob_dma = no_vmwait, no_barrier, oob_dma
+        # wave_shift / read_shift > 0: FOUR copies of the K loop, one per wave; wave w's DMA pieces (fragment reads) sit wave_shift * w
+        # (read_shift * w) gaps later than wave 0's, so the CU's four waves do not present their requests in the same cycles
+        self.wave_shift, self.read_shift = wave_shift, read_shift
+        self.stamps = stamps          # s_memtime around every barrier: cycles spent at it (sum, max) and in the whole loop -> asm outputs
+        self.copies = 4 if (wave_shift or read_shift) else 1
+
+
+# The shipped schedule is SCHEDS[0]; the others are A/B candidates (mm_set_option gemm_w4 = sid) and, behind -DMM_W4_DIAG, timing-only
+# builds that drop one ingredient (results wrong by design) to price it.
+SCHEDS = [
+    Sched(1, dma0=0, dma_stride=4),                 # shipped: a wave's 16 DMA pieces 4 MFMAs (64 cycles) apart over the whole of phase B
+    Sched(2, dma0=1, dma_stride=2),                 # round-4 first cut (pieces 2 MFMAs apart): -4 % (profiles/r04_gemm_w4.md)
+    Sched(3, dma0=0, dma_stride=4, coarse=False),   # counted lgkmcnt waits instead of one per K-step
+    # ---- timing-only builds (-DMM_W4_DIAG, tools/build_diag.sh): each drops one ingredient of schedule 1
+    Sched(111, dma0=0, dma_stride=4, no_dma=True, diag=True),
+    Sched(112, dma0=0, dma_stride=4, no_reads=True, diag=True),
+    Sched(113, dma0=0, dma_stride=4, no_sync=True, diag=True),
+    Sched(114, dma0=0, dma_stride=4, no_barrier=True, diag=True),
+    Sched(115, dma0=0, dma_stride=4, no_vmwait=True, diag=True),          # barrier + lgkmcnt only: the DMA is never waited for
+    Sched(117, dma0=0, dma_stride=4, oob_dma=True, diag=True),            # every DMA lane out of range: the instructions issue, nothing moves
+    Sched(104, dma0=0, dma_stride=4, no_dma=True, no_reads=True, no_sync=True, diag=True),      # MFMAs only
+    Sched(121, dma0=0, dma_stride=4, stamps=True, diag=True),             # s_memtime around every barrier (tools/w4_stamps.py)
+    Sched(105, dma0=0, dma_stride=4, wave_shift=1, diag=True),            # per-wave copies of the loop, DMA gaps staggered by wave
+]
 
 
 class Variant:
@@ -122,7 +156,7 @@ def desc_advance(X, step):
             f"s_sub_u32 s{d + 2}, s{d + 2}, {step}", f"s_cselect_b32 s{d + 2}, 0, s{d + 2}"]      # num_records saturates at 0
 
 
-def gen_variant(v):
+def gen_variant(v, sc):
     e = Emitter()
     kcA, kcB = v.kc["A"], v.kc["B"]
     stepA = "128" if kcA else f"s{S_SB + 1}"
@@ -140,12 +174,15 @@ def gen_variant(v):
         e.raw(f"s_lshl_b32 s{S_SB}, %[tb0], 2")          # K-step of a K-strided B = 64 rows = 4 x the 16-row piece stride
     if not kcA:
         e.raw(f"s_lshl_b32 s{S_SB + 1}, %[ta], 2")
-    # the tile's K-steps 0 and 1 are already in flight: the running descriptors start at K-step 2
+    # the tile's K-steps 0 and 1 are already in flight: the running descriptors enter at K-step 1 and phase A of K-step s moves
+    # them to K-step s + 2 before phase B issues that DMA
     for X, st in (("A", stepA), ("B", stepB)):
-        for _ in range(2):
-            for s in desc_advance(X, st):
-                e.raw(s)
-    e.raw(f"s_mov_b32 s{S_KD}, 2")
+        for s in desc_advance(X, st):
+            e.raw(s)
+    e.raw(f"s_mov_b32 s{S_KD}, 1")
+    if sc.oob_dma:
+        for q, val in enumerate(("s64", "s65", "0", "0x20000")):
+            e.raw(f"s_mov_b32 s{72 + q}, {val}")
     e.raw(f"s_sub_u32 s{S_LOOP}, %[nk], 1")
     e.raw(f"s_mov_b32 s{S_DST}, %[dst]")
     # per-piece DMA offsets: piece i of a wave = piece 0 + wave-uniform strides
@@ -166,7 +203,7 @@ def gen_variant(v):
             e.raw(f"v_mov_b32 v{vo}, %[voff{p}0]")
             e.raw(f"v_mov_b32 v{vo + 1}, %[voff{p}1]")
             for k in range(2, 8):
-                e.raw(f"v_add_u32 v{vo + k}, %[t{p}0], v{vo + k - 2}")
+                e.raw(f"v_add_u32 v{vo + k}, {'%[ta]' if X == 'A' else '%[tb0]'}, v{vo + k - 2}")
     # LDS read addresses
     for X, p in (("A", "a"), ("B", "b")):
         if v.kc[X]:
@@ -182,23 +219,39 @@ def gen_variant(v):
         e.lds(f, v.frag_reads(*f))
 
     # ------------------------------------------------------------------ one K-step
-    def kstep(first):
+    def kstep(first, wv):
         # ---- phase A
         reads = v.read_order(1)
         insts = [(f, s) for f in reads for s in [v.frag_reads(*f)]]
-        gaps = spread(len(insts), 0, 40)
+        gaps = [g + sc.read_shift * wv for g in spread(len(insts), *sc.ra)]
         aux = {g: [] for g in range(64)}
         for (f, s), g in zip(insts, gaps):
-            aux[g].append(("lds", f, s))
+            if not sc.no_reads:
+                aux[g].append(("lds", f, s))
         toggles = [f"v_xor_b32 v{r}, {STAGE}, v{r}" for X in "AB" for r in v.rd_regs(X)]      # after the last read of stage(s)
-        for s, g in zip(toggles, spread(len(toggles), 44, 62)):
+        for s, g in zip(toggles, spread(len(toggles), *sc.tog)):
             aux[g].append(("raw", s))
+        # bookkeeping for the DMA this K-step issues (phase B): advance the descriptors one K-step; at the end of the tile's K range
+        # switch to the next tile's descriptors (their K-step 0).  SCC chains (add / addc, sub / cselect, cmp / cmov) stay in order,
+        # two instructions per gap; nothing else in phase A writes SCC.
+        book = desc_advance("A", stepA) + desc_advance("B", stepB)
+        book += [f"s_add_u32 s{S_KD}, s{S_KD}, 1", f"s_cmp_eq_u32 s{S_KD}, %[nk]", f"s_cmov_b32 s{S_KD}, 0"]
+        for X, p in (("A", "na"), ("B", "nb")):
+            for q in range(3):
+                book.append(f"s_cmov_b32 s{S_DESC[X] + q}, %[{p}{q}]")
+        g0, n0 = sc.book0, 0
+        for s in book:
+            aux[g0].append(("raw", s))
+            n0 += 1
+            if n0 == 2:
+                g0, n0 = g0 + 1, 0
         m = 0
-        if COARSE_WAITS:
+        if sc.coarse and not sc.no_sync:
             e.lgkm_wait()
         for i in range(8):
             for j in range(8):
-                e.need([("A", 0, i), ("B", 0, j)])
+                if not sc.coarse and not sc.no_reads:
+                    e.need([("A", 0, i), ("B", 0, j)])
                 e.raw(mfma(i, j, 0, first))
                 for a in aux[m]:
                     if a[0] == "lds":
@@ -207,38 +260,51 @@ def gen_variant(v):
                         e.raw(a[1])
                 m += 1
         # ---- P
-        e.full_wait()
-        e.raw("s_barrier")
+        if not sc.no_sync:
+            if sc.no_vmwait:
+                e.lgkm_wait()
+            else:
+                e.full_wait()
+            if sc.stamps:
+                e.raw("s_memtime s[92:93]")
+            if not sc.no_barrier:
+                e.raw("s_barrier")
+            if sc.stamps:
+                e.raw("s_memtime s[94:95]")
+                e.raw("s_waitcnt lgkmcnt(0)")
+                e.raw("s_sub_u32 s98, s94, s92")
+                e.raw("s_add_u32 s90, s90, s98")
+                e.raw("s_max_u32 s91, s91, s98")
         # ---- phase B
         reads = v.read_order(0)
         insts = [(f, s) for f in reads for s in [v.frag_reads(*f)]]
         aux = {g: [] for g in range(64)}
-        for (f, s), g in zip(insts, spread(len(insts), 0, 44)):
-            aux[g].append(("lds", f, s))
+        for (f, s), g in zip(insts, [g + sc.read_shift * wv for g in spread(len(insts), *sc.rb)]):
+            if not sc.no_reads:
+                aux[g].append(("lds", f, s))
         k = 0
+        pre = []
         for X in "AB":
             for i in range(8):
-                aux[2 * k].append(("raw", f"s_add_u32 m0, s{S_DST}, {TILE_OFF[X] + i * 4096}"))
-                aux[2 * k + 1].append(("raw", f"buffer_load_dwordx4 v{V_VOFF[X] + i}, s[{S_DESC[X]}:{S_DESC[X] + 3}], 0 offen lds"))
+                g = sc.dma0 + sc.dma_stride * k + sc.wave_shift * wv          # the DMA's gap; M0 is written one gap earlier (a wait state)
+                m0w = ("raw", f"s_add_u32 m0, s{S_DST}, {TILE_OFF[X] + i * 4096}")
+                if g == 0:
+                    pre.append(m0w)
+                else:
+                    aux[g - 1].append(m0w)
+                if not sc.no_dma:
+                    d = 72 if sc.oob_dma else S_DESC[X]
+                    aux[g].append(("raw", f"buffer_load_dwordx4 v{V_VOFF[X] + i}, s[{d}:{d + 3}], 0 offen lds"))
                 k += 1
-        # bookkeeping behind the last DMA: advance the descriptors one K-step; at the end of the tile's K range switch to the
-        # next tile's descriptors (their K-step 0); flip the stage the next DMA refills
-        book = desc_advance("A", stepA) + desc_advance("B", stepB)
-        book += [f"s_add_u32 s{S_KD}, s{S_KD}, 1", f"s_cmp_eq_u32 s{S_KD}, %[nk]", f"s_cmov_b32 s{S_KD}, 0"]
-        for X, p in (("A", "na"), ("B", "nb")):
-            for q in range(3):
-                book.append(f"s_cmov_b32 s{S_DESC[X] + q}, %[{p}{q}]")
-        book.append(f"s_xor_b32 s{S_DST}, s{S_DST}, {STAGE}")
-        g0, n0 = 33, 0
-        for s in book:          # SCC chains (add / addc, sub / cselect, cmp / cmov) stay in order: two instructions per gap
-            aux[g0].append(("raw", s))
-            n0 += 1
-            if n0 == 2:
-                g0, n0 = g0 + 1, 0
+        assert sc.dma0 + sc.dma_stride * 15 + sc.wave_shift * 3 <= 63
+        aux[63].append(("raw", f"s_xor_b32 s{S_DST}, s{S_DST}, {STAGE}"))      # the stage the next K-step's DMA refills
         m = 0
+        for a in pre:
+            e.raw(a[1])
         for i in range(8):
             for j in range(8):
-                e.need([("A", 1, i), ("B", 1, j)])
+                if not sc.no_reads and sc.no_sync:
+                    e.need([("A", 1, i), ("B", 1, j)])
                 e.raw(mfma(i, j, 1, False))
                 for a in aux[m]:
                     if a[0] == "lds":
@@ -247,14 +313,38 @@ def gen_variant(v):
                         e.raw(a[1])
                 m += 1
 
-    kstep(True)                                          # K-step 0: C = 0
-    e.raw("L_w4_loop_%=:")
-    kstep(False)
-    e.raw(f"s_sub_u32 s{S_LOOP}, s{S_LOOP}, 1")
-    e.raw(f"s_cmp_lg_u32 s{S_LOOP}, 0")
-    e.raw("s_cbranch_scc1 L_w4_loop_%=")
+    if sc.stamps:
+        e.raw("s_mov_b32 s90, 0")
+        e.raw("s_mov_b32 s91, 0")
+        e.raw("s_memtime s[96:97]")
+    if sc.copies > 1:                                    # one copy of the loop per wave
+        for wv in range(1, sc.copies):
+            e.raw(f"s_cmp_eq_u32 %[wv], {wv}")
+            e.raw(f"s_cbranch_scc1 L_w4_wave{wv}_%=")
+    st0 = (e.lds_issued, dict(e.frag_last), e.done_upto)
+    for wv in range(sc.copies):
+        if wv:
+            e.raw(f"L_w4_wave{wv}_%=:")
+            e.lds_issued, e.frag_last, e.done_upto = st0[0], dict(st0[1]), st0[2]
+        kstep(True, wv)                                  # K-step 0: C = 0
+        e.raw(f"L_w4_loop{wv}_%=:")
+        kstep(False, wv)
+        e.raw(f"s_sub_u32 s{S_LOOP}, s{S_LOOP}, 1")
+        e.raw(f"s_cmp_lg_u32 s{S_LOOP}, 0")
+        e.raw(f"s_cbranch_scc1 L_w4_loop{wv}_%=")
+        if wv + 1 < sc.copies:
+            e.raw("s_branch L_w4_exit_%=")
+    if sc.copies > 1:
+        e.raw("L_w4_exit_%=:")
     # ------------------------------------------------------------------ exit
+    if sc.stamps:
+        e.raw("s_memtime s[92:93]")
     e.raw("s_waitcnt lgkmcnt(0)")                        # the last phase B's fragment reads land in v[128:191]
+    if sc.stamps:
+        e.raw("s_sub_u32 s98, s92, s96")
+        e.raw("s_mov_b32 %[o0], s90")
+        e.raw("s_mov_b32 %[o1], s91")
+        e.raw("s_mov_b32 %[o2], s98")
     e.raw("s_nop 7")                                     # MFMA results -> v_accvgpr_read (the epilogue's statements)
     e.raw("s_nop 7")
     e.raw("s_nop 7")
@@ -272,7 +362,7 @@ def operands(v):
         ops += [(f"{p}{q}", "s") for q in range(3)]
     ops += [("ta", "s")]
     ops += [("tb0", "s")] + ([("tb1", "s"), ("tb2", "s")] if v.kc["B"] else [])
-    ops += [("nk", "s"), ("dst", "s")]
+    ops += [("nk", "s"), ("dst", "s"), ("wv", "s")]
     return ops
 
 
@@ -281,18 +371,37 @@ def main():
     out = ["// GENERATED by gen_gemm_w4.py -- do not edit.  Main loop of gemm_bf16_w4_kernel (see the generator's header).", ""]
     clob = [f"v{r}" for r in range(92, 256)] + [f"a{r}" for r in range(256)] + [f"s{r}" for r in range(64, 90)] + ["memory", "scc"]
     out.append("#define MM_W4_CLOBBERS " + ", ".join(f'"{c}"' for c in clob))
+    out.append("#define MM_W4_CLOBBERS_DIAG MM_W4_CLOBBERS, " + ", ".join(f'"s{r}"' for r in range(90, 100)))
     out.append("")
-    for v in (Variant("NT", True, True), Variant("NN", True, False)):
-        body = gen_variant(v)
-        nm = sum(1 for s in body if s.startswith("v_mfma"))
-        out.append(f"// {v.name}: {len(body)} instructions, {nm} MFMAs (3 K-step bodies' worth: peeled first step + loop)")
-        out.append(f"#define MM_W4_ASM_{v.name} \\")
-        for s in body:
-            out.append(f'  "{s}\\n\\t" \\')
-        out.append('  ""')
+    out.append("#define MM_W4_SCHEDS_PRODUCT " + ", ".join(str(sc.sid) for sc in SCHEDS if not sc.diag))
+    out.append("#define MM_W4_SCHEDS_DIAG " + ", ".join(str(sc.sid) for sc in SCHEDS if sc.diag))
+    out.append("")
+    for v in (Variant("NT", True, True), Variant("NN", True, False), Variant("TN", False, False)):
+        for sc in SCHEDS:
+            body = gen_variant(v, sc)
+            nm = sum(1 for s in body if s.startswith("v_mfma"))
+            if sc.diag:
+                out.append("#ifdef MM_W4_DIAG")
+            out.append(f"// {v.name}, schedule {sc.sid}: {len(body)} instructions, {nm} MFMAs (peeled first K-step + loop body)")
+            out.append(f"#define MM_W4_ASM_{v.name}_S{sc.sid} \\")
+            for s in body:
+                out.append(f'  "{s}\\n\\t" \\')
+            out.append('  ""')
+            if sc.diag:
+                out.append("#endif")
         ops = operands(v)
         out.append(f"#define MM_W4_INPUTS_{v.name}(" + ", ".join("p_" + n for n, _ in ops) + ") \\")
         out.append("  " + ", ".join(f'[{n}] "{c}"(p_{n})' for n, c in ops))
+        # the statement for schedule SCHED (a template parameter of the kernel)
+        for diag in (False, True):
+            out.append(f"#define MM_W4_RUN_{v.name}{'_DIAG' if diag else ''}(SCHED, ...) \\")
+            first = True
+            for sc in SCHEDS:
+                if sc.diag != diag or sc.stamps:
+                    continue
+                out.append(f"  {'if' if first else 'else if'} constexpr (SCHED == {sc.sid}) asm volatile(MM_W4_ASM_{v.name}_S{sc.sid} : : MM_W4_INPUTS_{v.name}(__VA_ARGS__) : MM_W4_CLOBBERS); \\")
+                first = False
+            out.append("  else { }")
         out.append("")
     # accumulator read-out for the epilogue: chunk c = columns 64c .. 64c+63 of the wave's 128 (acc[i][4c + jj])
     for c in range(2):

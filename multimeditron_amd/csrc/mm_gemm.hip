@@ -1097,11 +1097,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
 // K >= 192 (the host sends anything else to the 8-wave kernel).
 // ------------------------------------------------------------------------------------------------------
 #include "mm_gemm_w4.inc"
+#ifdef MM_W4_DIAG
+__device__ unsigned g_w4_diag[256 * 4 * 4];        // schedule 121: per (workgroup, wave) cycles at the barrier (sum, max), loop cycles, tiles
+#endif
 
 __device__ __forceinline__ unsigned w4_sgpr(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
 
-template <bool B_KC, int EK>
+template <bool A_KC, bool B_KC, int EK, int SCHED>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
+  static_assert(A_KC || !B_KC, "NT, NN, TN");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bf16* A = (const bf16*)g.A;
   const bf16* B = (const bf16*)g.B;
@@ -1119,25 +1123,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   int pm, pn;
   block_to_tile(tile, g.nbm, g.nbn, pm, pn);
   int m0 = pm * 256, n0 = pn * nstep;
-  SRsrc ra = tile_rsrc<true>(A, g.lda, m0, g.M, g.K);
+  SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
   SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
   unsigned offa[8], offb[8];
-  dma_offsets<true, 256, 4>(offa, g.lda);
+  dma_offsets<A_KC, 256, 4>(offa, g.lda);
   dma_offsets<B_KC, 256, 4>(offb, g.ldb, swi);
-  const unsigned ldb2 = (unsigned)g.ldb * 2u;
+  const unsigned lda2 = (unsigned)g.lda * 2u, ldb2 = (unsigned)g.ldb * 2u;
   // K-steps 0 and 1 of the first tile; from here on every tile's asm statement issues K-steps 2.. and the next tile's 0 and 1
   dma_tile_inv<256, 4>(lds0, ra, offa, 0u);
   dma_tile_inv<256, 4>(lds0 + 32768u, rb, offb, 0u);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  dma_tile_inv<256, 4>(lds0 + 65536u, ra, offa, 128u);
+  dma_tile_inv<256, 4>(lds0 + 65536u, ra, offa, A_KC ? 128u : 64u * lda2);
   dma_tile_inv<256, 4>(lds0 + 65536u + 32768u, rb, offb, B_KC ? 128u : 64u * ldb2);
   // lane parts of the fragment addresses (frag_load2's formulas with the wave's first row block; + 2048 per 16 rows in the asm)
-  const unsigned voffa0 = offa[0], voffb0 = offb[0], voffb1 = offb[1];
+  const unsigned voffa0 = offa[0], voffa1 = offa[1], voffb0 = offb[0], voffb1 = offb[1];
   const int lr = l & 15, lg = l >> 4;
-  const unsigned rda_lo = (unsigned)((wm * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
-  const unsigned rda_hi = (unsigned)((wm * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
-  unsigned rdb_lo, rdb_hi;
+  unsigned rda_lo, rda_hi, rdb_lo, rdb_hi;
+  if constexpr (A_KC) {
+    rda_lo = (unsigned)((wm * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
+    rda_hi = (unsigned)((wm * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
+  } else {
+    const int q = lr >> 2, p = lr & 3, k = 8 * lg + q;
+    rda_lo = (unsigned)(k * 512 + p * 8);
+    rda_hi = (unsigned)(((wm * 8 + ks_swz(k)) & 15) * 32);
+  }
   if constexpr (B_KC) {
     rdb_lo = 32768u + (unsigned)((wn * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
     rdb_hi = 32768u + (unsigned)((wn * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
@@ -1147,7 +1157,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     rdb_hi = (unsigned)(((wn * 8 + ks_swz(k)) & 15) * 32);
   }
   // wave-uniform strides between a wave's DMA pieces (piece i = 8 rows at local row 8 w + 32 i; bits 0, 1, 2 of i)
-  const unsigned ta = w4_sgpr(64u * (unsigned)g.lda);
+  const unsigned ta = w4_sgpr(A_KC ? 32u * lda2 : 16u * lda2);       // A is never gathered: 32 rows per piece step (K-strided: 16 k-rows)
   unsigned tb0, tb1 = 0, tb2 = 0;
   if constexpr (B_KC) {
     if (swi > 0) { tb0 = (unsigned)swi * ldb2; tb1 = 32u * ldb2; tb2 = 64u * ldb2; }          // swiglu_row: bit 0 -> + I rows
@@ -1157,7 +1167,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     tb0 = 16u * ldb2;                               // 16 k-rows between pieces of equal parity
   }
   tb0 = w4_sgpr(tb0); tb1 = w4_sgpr(tb1); tb2 = w4_sgpr(tb2);
-  const unsigned nk_s = w4_sgpr((unsigned)nk);
+  const unsigned nk_s = w4_sgpr((unsigned)nk), wv_s = w4_sgpr((unsigned)w);
   unsigned sidx = 0;                                // K-steps streamed so far (ring position)
   while (tile < total) {
     const int next = tile + gridDim.x;
@@ -1168,28 +1178,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
       block_to_tile(next, g.nbm, g.nbn, qm, qn);
       nm0 = qm * 256;
       nn0 = qn * nstep;
-      const SRsrc nra = tile_rsrc<true>(A, g.lda, nm0, g.M, g.K), nrb = tile_rsrc<B_KC>(B, g.ldb, nn0, g.N, g.K);
+      const SRsrc nra = tile_rsrc<A_KC>(A, g.lda, nm0, g.M, g.K), nrb = tile_rsrc<B_KC>(B, g.ldb, nn0, g.N, g.K);
       na0 = nra.w0; na1 = nra.w1; na2 = nra.w2; nb0 = nrb.w0; nb1 = nrb.w1; nb2 = nrb.w2;
     }
     na0 = w4_sgpr(na0); na1 = w4_sgpr(na1); na2 = w4_sgpr(na2); nb0 = w4_sgpr(nb0); nb1 = w4_sgpr(nb1); nb2 = w4_sgpr(nb2);
     const unsigned st = (sidx & 1u) * 65536u;
     const unsigned a0 = ra.w0, a1 = ra.w1, a2 = ra.w2, b0 = rb.w0, b1 = rb.w1, b2 = rb.w2;
-    const unsigned rda0 = rda_lo + st, rda1 = rda_hi + st, rdb0 = rdb_lo + st;
+    const unsigned rda0 = rda_lo + st, rda1 = A_KC ? rda_hi + st : rda_hi, rdb0 = rdb_lo + st;
     const unsigned dst = w4_sgpr(st + (unsigned)w * 1024u);
     if constexpr (B_KC) {
       const unsigned rdb1 = rdb_hi + st;
-      asm volatile(MM_W4_ASM_NT
-                   :
-                   : MM_W4_INPUTS_NT(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1,
-                                     tb2, nk_s, dst)
-                   : MM_W4_CLOBBERS);
+      MM_W4_RUN_NT(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s)
+#ifdef MM_W4_DIAG
+      MM_W4_RUN_NT_DIAG(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s)
+      if constexpr (SCHED == 121) {
+        unsigned o0, o1, o2;
+        asm volatile(MM_W4_ASM_NT_S121
+                     : [o0] "=&s"(o0), [o1] "=&s"(o1), [o2] "=&s"(o2)
+                     : MM_W4_INPUTS_NT(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s)
+                     : MM_W4_CLOBBERS_DIAG);
+        if (l == 0 && blockIdx.x < 256) {
+          unsigned* d = g_w4_diag + (blockIdx.x * 4 + w) * 4;
+          d[0] += o0; d[1] = d[1] > o1 ? d[1] : o1; d[2] += o2; d[3] += 1;
+        }
+      }
+#endif
+    } else if constexpr (A_KC) {
+      const unsigned rdb1 = rdb_hi;
+      MM_W4_RUN_NN(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s)
+#ifdef MM_W4_DIAG
+      MM_W4_RUN_NN_DIAG(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s)
+#endif
     } else {
       const unsigned rdb1 = rdb_hi;
-      asm volatile(MM_W4_ASM_NN
-                   :
-                   : MM_W4_INPUTS_NN(voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0,
-                                     nk_s, dst)
-                   : MM_W4_CLOBBERS);
+      MM_W4_RUN_TN(SCHED, voffa0, voffa1, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s)
+#ifdef MM_W4_DIAG
+      MM_W4_RUN_TN_DIAG(SCHED, voffa0, voffa1, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s)
+#endif
     }
     sidx += (unsigned)nk;
     // epilogue: the accumulators leave a[0:255] in two halves of 64 columns = one wave tile of the 8-wave form each
@@ -1210,7 +1235,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     m0 = nm0;
     n0 = nn0;
     if (next < total) {
-      ra = tile_rsrc<true>(A, g.lda, m0, g.M, g.K);
+      ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
       rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
     }
   }
@@ -1716,12 +1741,23 @@ static int small_variant(int M, int N, int K) {
 }
 static int g_opt_epi_pipe = 1;      // pipelined, branch-free epilogue of the plain / SwiGLU-backward LDS-DMA kernels
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
-static int g_opt_w4 = 1;            // NT / NN 256x256 tiles on the 4-wave hand-scheduled kernel (gemm_bf16_w4_kernel); 0 = the 8-wave kernel (A/B)
+static int g_opt_w4 = [] { const char* e = getenv("MM_GEMM_W4"); return e ? atoi(e) : 1; }();            // (MM_GEMM_W4=0: A/B at step level) NT / NN 256x256 tiles on the 4-wave hand-scheduled kernel (gemm_bf16_w4_kernel); 0 = the 8-wave kernel (A/B)
 
 extern "C" int mm_attn_set_issue_waves(int v);
 int mm_attn_option(const char* name, int value);
 
 extern int g_adamw_blocks;    // mm_optim.hip
+
+#ifdef MM_W4_DIAG
+extern "C" int mm_w4_diag_read(unsigned* out, int reset) {      // diag builds only (not in the ABI header): 256 x 4 x 4 words
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_diag), sizeof(unsigned) * 256 * 4 * 4) != hipSuccess) return MM_ERR_LAUNCH;
+  if (reset) {
+    static unsigned zeros[256 * 4 * 4];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4_diag), zeros, sizeof(zeros)) != hipSuccess) return MM_ERR_LAUNCH;
+  }
+  return MM_OK;
+}
+#endif
 
 extern "C" int mm_set_option(const char* name, int value) {
   if (!name) return MM_ERR_ARG;
@@ -1737,7 +1773,7 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_epi_pipe")) { g_opt_epi_pipe = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
-  if (!strcmp(name, "gemm_w4")) { g_opt_w4 = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_w4")) { if (value < 0) return MM_ERR_ARG; g_opt_w4 = value; return MM_OK; }      // 0 off, 1 the shipped schedule, n > 1: gen_gemm_w4.py SCHEDS
   if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 6) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -2037,20 +2073,32 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
       // NT / NN 256x256 tiles: the 4-wave kernel (A K-contiguous, whole K-steps, the epilogue kinds it instantiates)
       const bool acts = (epilogue & (MM_EPI_GELU_ERF | MM_EPI_QUICK_GELU | MM_EPI_GELU_TANH)) != 0;
-      if (g_opt_w4 && variant == 2 && layout != MM_GEMM_TN && (K & 63) == 0 && K >= 192 && !g.ss && !acts) {
+      // (a last round at most half full goes to the 8-wave kernel, which cuts those tiles in two: g.tail below)
+      const int64_t rem4 = g_opt_persist ? nwg % ncu : 0;
+      const bool tail4 = g_opt_tail && !g.swi_I && !g.rope_cols && rem4 > 0 && 2 * rem4 <= ncu;
+      if (g_opt_w4 && variant == 2 && (K & 63) == 0 && K >= 192 && !g.ss && !acts && !tail4) {
         const int64_t nb4 = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
         dim3 grid4((unsigned)nb4), block4(256);
-#define MM_LAUNCH_W4(BKC, EK)                                                                                            \
+#define MM_LAUNCH_W4(AKC, BKC, EK, SCHED)                                                                                    \
   do {                                                                                                                   \
-    auto kfn = gemm_bf16_w4_kernel<BKC, EK>;                                                                             \
+    auto kfn = gemm_bf16_w4_kernel<AKC, BKC, EK, SCHED>;                                                                     \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     hipLaunchKernelGGL(kfn, grid4, block4, lds, s, g);                                                                   \
   } while (0)
-        if (g.rope_cols) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, 4); }
-        else if (g.swi_I) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, 3); }
-        else if (epilogue & MM_EPI_SWIGLU_BWD) { if (layout != MM_GEMM_NN) return MM_ERR_ARG; MM_LAUNCH_W4(false, 2); }
-        else if (layout == MM_GEMM_NT) MM_LAUNCH_W4(true, 0);
-        else MM_LAUNCH_W4(false, 0);
+#define MM_W4_CASE(AKC, BKC, SCHED) case SCHED: MM_LAUNCH_W4(AKC, BKC, 0, SCHED); break;
+#ifdef MM_W4_DIAG
+#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 104) MM_W4_CASE(AKC, BKC, 105) MM_W4_CASE(AKC, BKC, 111) MM_W4_CASE(AKC, BKC, 112) MM_W4_CASE(AKC, BKC, 113) MM_W4_CASE(AKC, BKC, 114) MM_W4_CASE(AKC, BKC, 115) MM_W4_CASE(AKC, BKC, 117) MM_W4_CASE(AKC, BKC, 121)
+#else
+#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3)
+#endif
+        if (g.rope_cols) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, true, 4, 1); }
+        else if (g.swi_I) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, true, 3, 1); }
+        else if (epilogue & MM_EPI_SWIGLU_BWD) { if (layout != MM_GEMM_NN) return MM_ERR_ARG; MM_LAUNCH_W4(true, false, 2, 1); }
+        else if (layout == MM_GEMM_NT) { switch (g_opt_w4) { MM_W4_CASES(true, true) default: MM_LAUNCH_W4(true, true, 0, 1); } }
+        else if (layout == MM_GEMM_NN) { switch (g_opt_w4) { MM_W4_CASES(true, false) default: MM_LAUNCH_W4(true, false, 0, 1); } }
+        else { switch (g_opt_w4) { MM_W4_CASES(false, false) default: MM_LAUNCH_W4(false, false, 0, 1); } }
+#undef MM_W4_CASES
+#undef MM_W4_CASE
 #undef MM_LAUNCH_W4
         MM_CHECK_LAUNCH();
         return MM_OK;

@@ -6,9 +6,9 @@ cd "$(dirname "$0")/.."
 name=$1; defs=$2
 mkdir -p build_diag/obj_$name
 objs=""
-for f in mm_gemm mm_attn mm_rowwise mm_embed mm_optim mm_debug mm_comm mm_image; do
+for f in mm_gemm mm_attn mm_rowwise mm_embed mm_optim mm_debug mm_comm mm_image mm_xattn; do
   o=multimeditron_amd/csrc/build/$f.o
-  if [ $f = mm_gemm ] || [ $f = mm_attn ]; then
+  if [ $f = mm_gemm ] || { [ $f = mm_attn ] && [ -z "$MM_DIAG_GEMM_ONLY" ]; }; then
     o=build_diag/obj_$name/$f.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $defs -c multimeditron_amd/csrc/$f.hip -o $o &
   fi

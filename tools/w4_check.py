@@ -12,7 +12,8 @@ import torch
 from multimeditron_amd import kernels as K
 from multimeditron_amd._lib import lib
 
-NT, NN = 0, 1
+NT, NN, TN = 0, 1, 2
+LN = {0: 'NT', 1: 'NN', 2: 'TN'}
 
 
 def set_opt(name, v):
@@ -48,9 +49,10 @@ def check():
     bad = 0
     set_opt("gemm_kernel", 3)             # every case on the 256x256 tile (small problems would pick a smaller one)
     cases = [(NT, 8192, 4096, 4096), (NT, 5112, 6144, 4096), (NT, 1000, 1544, 320), (NT, 2049, 4104, 1024), (NT, 8192, 4096, 14336),
-             (NN, 8192, 4096, 6144), (NN, 5112, 4096, 4096), (NN, 1111, 1032, 448), (NN, 4096, 14336, 4096), (NN, 300, 520, 192)]
+             (NN, 8192, 4096, 6144), (NN, 5112, 4096, 4096), (NN, 1111, 1032, 448), (NN, 4096, 14336, 4096), (NN, 300, 520, 192),
+             (TN, 4096, 4096, 8192), (TN, 6144, 4096, 8192), (TN, 1000, 1544, 320), (TN, 4096, 14336, 8192), (TN, 777, 2056, 1024)]
     for lay, M, N, Kd in cases:
-        a = rnd(g, M, Kd)
+        a = rnd(g, M, Kd) if lay != TN else rnd(g, Kd, pad64(M))[:, :M]
         b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, pad64(N))[:, :N]
         res = rnd(g, M, N)
         for kind in ("plain", "residual", "accumulate"):
@@ -70,11 +72,11 @@ def check():
                     print(f"  MISMATCH max {float(d.max()):.4g} at rows {rows[:4].tolist()}..{rows[-1:].tolist()} ({rows.numel()}) cols {cols[:4].tolist()}..{cols[-1:].tolist()} ({cols.numel()})")
                     bad += 1
                     break
-            ref = a.float() @ (b.float().t() if lay == NT else b.float())
+            ref = (a.float() if lay != TN else a.float().t()) @ (b.float().t() if lay == NT else b.float())
             if kind != "plain":
                 ref = ref + res.float()
             err = float((o1.float() - ref).norm() / ref.norm())
-            print(f"{'NT' if lay == NT else 'NN'} M={M} N={N} K={Kd} {kind}: {'bit-identical' if ok else 'DIFFERENT'}  rel-L2 vs fp32 {err:.2e}", flush=True)
+            print(f"{LN[lay]} M={M} N={N} K={Kd} {kind}: {'bit-identical' if ok else 'DIFFERENT'}  rel-L2 vs fp32 {err:.2e}", flush=True)
     # fused gate|up + SwiGLU (NT), SwiGLU backward on the down_proj dgrad (NN), q|k|v + RoPE (NT)
     for M, I, H in ((8192, 14336, 4096), (1000, 1024, 512), (5112, 2048, 4096)):
         x, wgu = rnd(g, M, H), rnd(g, 2 * I, H) * 0.05
@@ -100,6 +102,49 @@ def check():
     set_opt("gemm_kernel", 0)
     print("CHECK", "FAILED" if bad else "OK", flush=True)
     return bad
+
+
+def timing_scheds(scheds, quick):
+    """interleaved timing of several schedules of the 4-wave kernel (gen_gemm_w4.py SCHEDS; 0 = the 8-wave kernel)"""
+    T = 8192
+    shapes = [(NT, T, 4096, 4096), (NT, T, 28672, 4096), (NT, T, 4096, 14336), (NN, T, 4096, 4096), (NN, T, 14336, 4096), (NN, T, 4096, 28672),
+              (TN, 4096, 4096, T), (TN, 28672, 4096, T), (TN, 4096, 14336, T)]
+    if quick:
+        shapes = [shapes[0], shapes[3], shapes[6]]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    tot = {m: 0.0 for m in scheds}
+    for lay, M, N, Kd in shapes:
+        a = rnd(g, M, Kd) if lay != TN else rnd(g, Kd, M)
+        b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, N)
+        c = torch.empty(M, pad64(N), device="cuda", dtype=torch.bfloat16)[:, :N]
+        res = {m: [] for m in scheds}
+        set_opt("gemm_w4", 0)
+        ref = K.gemm(lay, a, b, M, N, Kd, out=c).clone()
+        for mode in scheds:               # product schedules must give the 8-wave kernel's bits (diag ones, >= 100, are wrong by design)
+            if 0 < mode < 100:
+                set_opt("gemm_w4", mode)
+                c.zero_()
+                K.gemm(lay, a, b, M, N, Kd, out=c)
+                if not torch.equal(c, ref):
+                    print(f"  schedule {mode}: DIFFERENT from the 8-wave kernel", flush=True)
+        for rnd_ in range(5):
+            for mode in scheds:
+                set_opt("gemm_w4", mode)
+                K.gemm(lay, a, b, M, N, Kd, out=c)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    K.gemm(lay, a, b, M, N, Kd, out=c)
+                e1.record()
+                torch.cuda.synchronize()
+                res[mode].append(e0.elapsed_time(e1) / 3)
+        fl = 2.0 * M * N * Kd
+        med = {m: sorted(v)[len(v) // 2] for m, v in res.items()}
+        for m in med:
+            tot[m] += med[m]
+        print(f"{LN[lay]} M={M:6d} N={N:6d} K={Kd:6d}  " + "  ".join(f"s{m}: {fl / med[m] / 1e9:6.0f}" for m in scheds), flush=True)
+    set_opt("gemm_w4", 1)
+    print("TOTAL ms", {m: round(v, 3) for m, v in tot.items()}, flush=True)
 
 
 def timing(quick):
@@ -136,6 +181,10 @@ def timing(quick):
 
 
 if __name__ == "__main__":
+    sch = [a for a in sys.argv if a.startswith("--scheds=")]
+    if sch:
+        timing_scheds([int(x) for x in sch[0][9:].split(",")], "--quick" in sys.argv)
+        sys.exit(0)
     rc = 0
     if "--time-only" not in sys.argv:
         rc = check()
