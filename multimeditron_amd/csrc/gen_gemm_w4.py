@@ -261,20 +261,22 @@ def gen_variant(v, sc):
                 m += 1
         # ---- P
         if not sc.no_sync:
+            if sc.stamps:
+                e.raw("s_memtime s[92:93]")
             if sc.no_vmwait:
                 e.lgkm_wait()
             else:
                 e.full_wait()
-            if sc.stamps:
-                e.raw("s_memtime s[92:93]")
             if not sc.no_barrier:
                 e.raw("s_barrier")
             if sc.stamps:
                 e.raw("s_memtime s[94:95]")
                 e.raw("s_waitcnt lgkmcnt(0)")
                 e.raw("s_sub_u32 s98, s94, s92")
-                e.raw("s_add_u32 s90, s90, s98")
-                e.raw("s_max_u32 s91, s91, s98")
+                if first:
+                    e.raw("s_mov_b32 s91, s98")                  # the tile's first P: waits for the previous tile's epilogue stores too
+                else:
+                    e.raw("s_add_u32 s90, s90, s98")
         # ---- phase B
         reads = v.read_order(0)
         insts = [(f, s) for f in reads for s in [v.frag_reads(*f)]]
@@ -345,6 +347,8 @@ def gen_variant(v, sc):
         e.raw("s_mov_b32 %[o0], s90")
         e.raw("s_mov_b32 %[o1], s91")
         e.raw("s_mov_b32 %[o2], s98")
+        e.raw("s_mov_b32 %[o3], s96")
+        e.raw("s_mov_b32 %[o4], s92")
     e.raw("s_nop 7")                                     # MFMA results -> v_accvgpr_read (the epilogue's statements)
     e.raw("s_nop 7")
     e.raw("s_nop 7")
@@ -403,17 +407,29 @@ def main():
                 first = False
             out.append("  else { }")
         out.append("")
-    # accumulator read-out for the epilogue: chunk c = columns 64c .. 64c+63 of the wave's 128 (acc[i][4c + jj])
+    # accumulator read-out for the epilogues.  w4_read_acc_c{c}: columns 64c .. 64c+63 of the wave's 128 (acc[i][4c + jj]), the
+    # 8-wave form's wave tile; w4_read_acc_b{ip}{c}: rows 32 ip .. 32 ip + 31 of that (two row blocks) for the row-major epilogue
+    def rd(n, dst):
+        return ("  { float t0, t1, t2, t3; asm volatile(\"v_accvgpr_read_b32 %0, a" + str(n) + "\\n\\tv_accvgpr_read_b32 %1, a" + str(n + 1) +
+                "\\n\\tv_accvgpr_read_b32 %2, a" + str(n + 2) + "\\n\\tv_accvgpr_read_b32 %3, a" + str(n + 3) +
+                "\" : \"=v\"(t0), \"=v\"(t1), \"=v\"(t2), \"=v\"(t3)); " + dst + " = f32x4{t0, t1, t2, t3}; }")
     for c in range(2):
         out.append(f"__device__ __forceinline__ void w4_read_acc_c{c}(f32x4 (&acc)[8][4]) {{")
         for i in range(8):
             for jj in range(4):
-                n = ACC(i, 4 * c + jj)
-                out.append("  { float t0, t1, t2, t3; asm volatile(\"v_accvgpr_read_b32 %0, a" + str(n) + "\\n\\tv_accvgpr_read_b32 %1, a" + str(n + 1) +
-                           "\\n\\tv_accvgpr_read_b32 %2, a" + str(n + 2) + "\\n\\tv_accvgpr_read_b32 %3, a" + str(n + 3) +
-                           "\" : \"=v\"(t0), \"=v\"(t1), \"=v\"(t2), \"=v\"(t3)); acc[" + str(i) + "][" + str(jj) + "] = f32x4{t0, t1, t2, t3}; }")
+                out.append(rd(ACC(i, 4 * c + jj), f"acc[{i}][{jj}]"))
         out.append("}")
         out.append("")
+    out.append("template <int IP, int C> __device__ __forceinline__ void w4_read_acc_blk(f32x4 (&acc)[2][4]) {")
+    for ip in range(4):
+        for c in range(2):
+            out.append(f"  if constexpr (IP == {ip} && C == {c}) {{")
+            for ii in range(2):
+                for jj in range(4):
+                    out.append("  " + rd(ACC(2 * ip + ii, 4 * c + jj), f"acc[{ii}][{jj}]"))
+            out.append("  }")
+    out.append("}")
+    out.append("")
     path = os.path.join(here, "mm_gemm_w4.inc")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")

@@ -19,6 +19,7 @@
 //
 // f32 path (parity only): 64x64x16 tiles on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 #include "mm_common.h"
@@ -55,6 +56,9 @@ struct GemmArgs {
   // 256x256 tile fills half 0 and zeroes half 1, the half tiles of the last round fill their own half: the slot of a value does
   // not depend on how the tiles were scheduled (persistent / one tile per workgroup, tail split or not).
   float* ss;
+  int stream_epi;               // 4-wave kernel: the plain epilogue without waits between its stores (gemm_epilogue_plain_stream)
+  int stagger;                  // 4-wave kernel: start delay in cycles per (blockIdx.x & 7) -- spreads the workgroups' epilogue bursts (experiment)
+  int rowmajor;                 // 4-wave kernel: the plain epilogue in its row-major form (16-byte accesses; set by the host when alignment allows)
 };
 constexpr int MM_EPI_SWIGLU_BWD = 1 << 20;   // internal epilogue flag (mm_gemm_swiglu_bwd), not part of the ABI enum
 
@@ -171,8 +175,8 @@ __device__ __forceinline__ bf16x8 frag_load(const char* tile, int xb, int ks) {
 // in the 256x256 kernel (128 accumulator registers per lane) the extra path cost 528 bytes of scratch per lane and 10 % of the
 // GEMM's speed for EVERY launch -- found by the step going from 401 to 440 ms.
 template <int MREP, int NREP, bool ALLOW_PRE, bool ACT = true>
-__device__ __forceinline__ void gemm_epilogue_plain(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
-  const int l = threadIdx.x & 63;
+__device__ __forceinline__ void gemm_epilogue_plain(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int lane = -1) {
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63);
   bf16* C = (bf16*)g.C;
   const bf16* bias = (const bf16*)g.bias;
   const bf16* R = (const bf16*)g.residual;
@@ -259,8 +263,8 @@ __device__ __forceinline__ void gemm_epilogue_plain(const GemmArgs& g, f32x4 (&a
 // MM_EPI_SWIGLU_BWD (mm_gemm_swiglu_bwd) as its own epilogue: kept out of the plain one, whose instruction count and register
 // pressure every GEMM launch pays for.
 template <int MREP, int NREP>
-__device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
-  const int l = threadIdx.x & 63;
+__device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int lane = -1) {
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63);
   bf16* C = (bf16*)g.C;
 #pragma unroll
   for (int i = 0; i < MREP; ++i) {
@@ -304,8 +308,8 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x
 constexpr unsigned EPI_OOB = 0xFFFFFFFFu;
 
 template <int MREP, int NREP, bool SUMSQ = false>
-__device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int ss_slot = 0) {
-  const int l = threadIdx.x & 63;
+__device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int ss_slot = 0, int lane = -1) {
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63);      // lane: the caller's (opaque) copy of the lane index, see gemm_bf16_w4_kernel
   float ssq = 0.f;
   mw = __builtin_amdgcn_readfirstlane(mw);
   nw = __builtin_amdgcn_readfirstlane(nw);
@@ -410,9 +414,72 @@ __device__ __forceinline__ void gemm_epilogue_plain_pipe(const GemmArgs& g, f32x
   }
 }
 
+// ---- the plain epilogue with NO wait between its stores (round 4) -----------------------------------------------------------------
+// gemm_epilogue_plain_pipe decides residual / accumulate at run time, so its counted waits (`s_waitcnt vmcnt(7)` in front of every
+// store: "the loads of the next row block may be in flight") are there in the plain case too, where the only vector-memory
+// operations are the stores themselves: at most 8 stores of a wave are ever outstanding and a 256x256 tile's epilogue takes ~21 000
+// cycles, 13 % of a K = 4096 tile (tools/w4_stamps.py; vmcnt retires in issue order, a store ~2 us after its issue).  MODE is a
+// compile-time parameter here: 0 = no loads at all -> no wait, the stores stream; 1 (residual) / 2 (accumulate) = every load of the
+// wave tile is requested first, ONE wait, then the stores stream.  Same arithmetic, same rounding points: bit-identical output.
+template <int MREP, int NREP, int MODE>
+__device__ __forceinline__ void gemm_epilogue_plain_stream(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int lane) {
+  const int l = lane;
+  mw = __builtin_amdgcn_readfirstlane(mw);
+  nw = __builtin_amdgcn_readfirstlane(nw);
+  const bool has_bias = (g.epi & MM_EPI_BIAS) != 0;
+  const int rows = g.M - mw;
+  auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)rows * g.ldc * 2);
+  auto rl = MODE == 1 ? make_rsrc((const bf16*)g.residual + (int64_t)mw * g.ldr, (int64_t)rows * g.ldr * 2) : rc;
+  const int ldl = MODE == 1 ? g.ldr : g.ldc;
+  unsigned colb[NREP];
+  float bv[NREP][4];
+#pragma unroll
+  for (int j = 0; j < NREP; ++j) {
+    const int n = nw + j * 16 + 4 * (l >> 4);
+    colb[j] = n + 3 < g.N ? (unsigned)n * 2u : EPI_OOB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+    if (has_bias && n + 3 < g.N) {
+      const bf16x4 b4 = *(const bf16x4*)((const bf16*)g.bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = (float)b4[r];
+    }
+  }
+  u32x2 lbuf[MODE ? MREP : 1][NREP];
+  if constexpr (MODE != 0) {
+#pragma unroll
+    for (int i = 0; i < MREP; ++i) {
+      const unsigned rowl = (unsigned)((i * 16 + (l & 15)) * ldl) * 2u;
+#pragma unroll
+      for (int j = 0; j < NREP; ++j) lbuf[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rl, colb[j] == EPI_OOB ? EPI_OOB : rowl + colb[j], 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MREP; ++i) {
+    const unsigned rowc = (unsigned)((i * 16 + (l & 15)) * g.ldc) * 2u;
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (has_bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
+      }
+      if constexpr (MODE != 0) {
+        const bf16x4 lv = __builtin_bit_cast(bf16x4, lbuf[i][j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)lv[r];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rc, colb[j] == EPI_OOB ? EPI_OOB : rowc + colb[j], 0, 0);
+    }
+  }
+}
+
 template <int MREP, int NREP>
-__device__ __forceinline__ void gemm_epilogue_swiglu_bwd_pipe(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
-  const int l = threadIdx.x & 63;
+__device__ __forceinline__ void gemm_epilogue_swiglu_bwd_pipe(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int lane = -1) {
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63);
   mw = __builtin_amdgcn_readfirstlane(mw);
   nw = __builtin_amdgcn_readfirstlane(nw);
   const int rows = g.M - mw;
@@ -466,26 +533,26 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd_pipe(const GemmArgs& g,
 // EK == 0 / EK == 2 epilogue of the LDS-DMA kernels.  The pipelined forms address a wave tile with 32-bit byte offsets: the host
 // (gemm_launch) sends a problem whose leading dimensions do not allow that to the register-staged kernel.
 template <int MREP, int NREP>
-__device__ __forceinline__ void gemm_epilogue_ek0(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+__device__ __forceinline__ void gemm_epilogue_ek0(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int lane = -1) {
 #if MM_GEMM_EPI_PIPE == 2                 // A/B build: both epilogues compiled in, chosen by mm_set_option("gemm_epi_pipe")
-  if (!g.pipe) { gemm_epilogue_plain<MREP, NREP, false, false>(g, acc, mw, nw); return; }
+  if (!g.pipe) { gemm_epilogue_plain<MREP, NREP, false, false>(g, acc, mw, nw, lane); return; }
 #endif
 #if MM_GEMM_EPI_PIPE
-  gemm_epilogue_plain_pipe<MREP, NREP>(g, acc, mw, nw);
+  gemm_epilogue_plain_pipe<MREP, NREP>(g, acc, mw, nw, 0, lane);
 #else
-  gemm_epilogue_plain<MREP, NREP, false, false>(g, acc, mw, nw);
+  gemm_epilogue_plain<MREP, NREP, false, false>(g, acc, mw, nw, lane);
 #endif
 }
 
 template <int MREP, int NREP>
-__device__ __forceinline__ void gemm_epilogue_ek2(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw) {
+__device__ __forceinline__ void gemm_epilogue_ek2(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int nw, int lane = -1) {
 #if MM_GEMM_EPI_PIPE == 2
-  if (!g.pipe) { gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, mw, nw); return; }
+  if (!g.pipe) { gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, mw, nw, lane); return; }
 #endif
 #if MM_GEMM_EPI_PIPE
-  gemm_epilogue_swiglu_bwd_pipe<MREP, NREP>(g, acc, mw, nw);
+  gemm_epilogue_swiglu_bwd_pipe<MREP, NREP>(g, acc, mw, nw, lane);
 #else
-  gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, mw, nw);
+  gemm_epilogue_swiglu_bwd<MREP, NREP>(g, acc, mw, nw, lane);
 #endif
 }
 
@@ -588,8 +655,8 @@ constexpr int G_BK = 64;
 // stores) and act = silu(gate) * up computed from those rounded values exactly as swiglu_fwd_kernel does: bit-identical
 // to GEMM + mm_swiglu_fwd, one pass less over [M, 2I] and one launch less per layer.
 template <int MREP, int NREP>
-__device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int fw) {
-  const int l = threadIdx.x & 63;
+__device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int fw, int lane = -1) {
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63);
   bf16* GU = (bf16*)g.C;
   bf16* ACT = (bf16*)g.C2;
   const int I = g.swi_I;
@@ -625,9 +692,9 @@ __device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&
 // are stored unrotated.  Table rows and the rows of C go through the buffer range check (descriptors anchored at the wave's
 // first row); the loads of row block i + 1 are requested before block i is rotated and stored.
 template <int MREP, int NREP>
-__device__ __forceinline__ void gemm_epilogue_rope(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int n0, int wn) {
+__device__ __forceinline__ void gemm_epilogue_rope(const GemmArgs& g, f32x4 (&acc)[MREP][NREP], int mw, int n0, int wn, int lane = -1) {
   static_assert(NREP == 4, "a wave owns 64 columns: two 16-column tiles of d and their partners d + 64");
-  const int l = threadIdx.x & 63;
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63);
   mw = __builtin_amdgcn_readfirstlane(mw);
   const int hb = __builtin_amdgcn_readfirstlane(n0 + (wn >> 1) * 128);          // first column of the wave's head
   const int dlo = __builtin_amdgcn_readfirstlane((wn & 1) * 32);
@@ -1098,8 +1165,99 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
 // ------------------------------------------------------------------------------------------------------
 #include "mm_gemm_w4.inc"
 #ifdef MM_W4_DIAG
-__device__ unsigned g_w4_diag[256 * 4 * 4];        // schedule 121: per (workgroup, wave) cycles at the barrier (sum, max), loop cycles, tiles
+__device__ unsigned g_w4_diag[256 * 4 * 7];        // schedule 121: per (workgroup, wave) cycles at the barrier (sum, max), loop cycles, tiles
 #endif
+
+// ---- row-major epilogue of the 4-wave kernel (EK == 0: bias / residual / accumulate) -------------------------------------------
+// In the accumulator layout a lane owns 4 consecutive columns of a row and a wave-wide store covers 16 rows x 32 bytes: 64 such
+// stores per wave and tile, each split into 16 partial-line writes.  Stamps (tools/w4_stamps.py) put the 256x256 tile's epilogue at
+// ~21 000 cycles -- 13 % of a K = 4096 tile -- almost all of it store ISSUE.  Here 32 rows x 64 columns of fp32 accumulators at a
+// time go through the wave's 8 KB of spare LDS (XOR-swizzled 16-byte chunks: conflict-free both ways) and come back with a lane
+// owning 8 consecutive columns: residual / C are read and C is written 16 bytes per lane, a wave-wide access = 8 rows x one full
+// 128-byte line.  Arithmetic and rounding points are those of gemm_epilogue_plain_pipe (acc + bias + residual + C, one rounding):
+// bit-identical output.  Rows >= M and column groups >= N fall to the buffer range check (the host requires N % 8 == 0).
+template <int IP, int C, int MODE>
+__device__ __forceinline__ void w4_rm_block(const GemmArgs& g, char* xp, __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rr, unsigned colb,
+                                            const float (&bv)[8], bool has_bias, int l) {
+  constexpr bool has_res = MODE == 1, has_acc = MODE == 2;
+  const int wr = l & 15, wq = l >> 4, r8 = l >> 3, c8 = l & 7;
+  f32x4 a[2][4];
+  w4_read_acc_blk<IP, C>(a);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int row = ii * 16 + wr, ch = jj * 4 + wq;
+      *(f32x4*)(xp + row * 256 + ((ch ^ (row & 15)) * 16)) = a[ii][jj];
+    }
+  __builtin_amdgcn_wave_barrier();
+  u32x4 rbuf[4], cbuf[4];
+  unsigned off[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = IP * 32 + it * 8 + r8;
+    off[it] = colb == EPI_OOB ? EPI_OOB : (unsigned)(row * g.ldc) * 2u + colb;
+    if (has_res) rbuf[it] = __builtin_amdgcn_raw_buffer_load_b128(rr, colb == EPI_OOB ? EPI_OOB : (unsigned)(row * g.ldr) * 2u + colb, 0, 0);
+    if (has_acc) cbuf[it] = __builtin_amdgcn_raw_buffer_load_b128(rc, off[it], 0, 0);
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + r8;
+    const f32x4 lo = *(const f32x4*)(xp + row * 256 + (((2 * c8) ^ (row & 15)) * 16));
+    const f32x4 hi = *(const f32x4*)(xp + row * 256 + (((2 * c8 + 1) ^ (row & 15)) * 16));
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (has_bias) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += bv[r];
+    }
+    if (has_res) {
+      const bf16x8 rv = __builtin_bit_cast(bf16x8, rbuf[it]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+    }
+    if (has_acc) {
+      const bf16x8 cv = __builtin_bit_cast(bf16x8, cbuf[it]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += (float)cv[r];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off[it], 0, 0);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int C, int MODE>
+__device__ __forceinline__ void w4_rm_half(const GemmArgs& g, char* xp, __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rr, int nw, bool has_bias, int l) {
+  const int n = nw + C * 64 + (l & 7) * 8;                  // the lane's 8 columns (N % 8 == 0: whole or absent)
+  const unsigned colb = n < g.N ? (unsigned)n * 2u : EPI_OOB;
+  float bv[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) bv[r] = 0.f;
+  if (has_bias && n < g.N) {
+    const bf16x8 b8 = *(const bf16x8*)((const bf16*)g.bias + n);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bv[r] = (float)b8[r];
+  }
+  w4_rm_block<0, C, MODE>(g, xp, rc, rr, colb, bv, has_bias, l);
+  w4_rm_block<1, C, MODE>(g, xp, rc, rr, colb, bv, has_bias, l);
+  w4_rm_block<2, C, MODE>(g, xp, rc, rr, colb, bv, has_bias, l);
+  w4_rm_block<3, C, MODE>(g, xp, rc, rr, colb, bv, has_bias, l);
+}
+
+template <int MODE>
+__device__ __forceinline__ void w4_epilogue_rowmajor(const GemmArgs& g, char* xp, int mw, int nw, int l) {
+  mw = __builtin_amdgcn_readfirstlane(mw);
+  nw = __builtin_amdgcn_readfirstlane(nw);
+  const bool has_bias = (g.epi & MM_EPI_BIAS) != 0;
+  const int rows = g.M - mw;
+  auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)rows * g.ldc * 2);
+  auto rr = MODE == 1 ? make_rsrc((const bf16*)g.residual + (int64_t)mw * g.ldr, (int64_t)rows * g.ldr * 2) : rc;
+  w4_rm_half<0, MODE>(g, xp, rc, rr, nw, has_bias, l);
+  w4_rm_half<1, MODE>(g, xp, rc, rr, nw, has_bias, l);
+}
 
 __device__ __forceinline__ unsigned w4_sgpr(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
 
@@ -1120,6 +1278,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   if (tile >= total) return;
   const int swi = (EK == 3) ? g.swi_I : (EK == 4 ? -1 : 0);       // B-row gather of the fused gate|up / RoPE tiles (gather_row)
   const int nstep = swi > 0 ? 128 : 256;
+  if (g.stagger > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), wait = (unsigned long long)g.stagger * (blockIdx.x & 7);
+    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
   int pm, pn;
   block_to_tile(tile, g.nbm, g.nbn, pm, pn);
   int m0 = pm * 256, n0 = pn * nstep;
@@ -1169,6 +1331,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   tb0 = w4_sgpr(tb0); tb1 = w4_sgpr(tb1); tb2 = w4_sgpr(tb2);
   const unsigned nk_s = w4_sgpr((unsigned)nk), wv_s = w4_sgpr((unsigned)w);
   unsigned sidx = 0;                                // K-steps streamed so far (ring position)
+#ifdef MM_W4_DIAG
+  unsigned w4_diag_end = 0;
+#endif
   while (tile < total) {
     const int next = tile + gridDim.x;
     int nm0 = 0, nn0 = 0;
@@ -1192,15 +1357,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
 #ifdef MM_W4_DIAG
       MM_W4_RUN_NT_DIAG(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s)
       if constexpr (SCHED == 121) {
-        unsigned o0, o1, o2;
+        unsigned o0, o1, o2, o3, o4;
         asm volatile(MM_W4_ASM_NT_S121
-                     : [o0] "=&s"(o0), [o1] "=&s"(o1), [o2] "=&s"(o2)
+                     : [o0] "=&s"(o0), [o1] "=&s"(o1), [o2] "=&s"(o2), [o3] "=&s"(o3), [o4] "=&s"(o4)
                      : MM_W4_INPUTS_NT(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s)
                      : MM_W4_CLOBBERS_DIAG);
         if (l == 0 && blockIdx.x < 256) {
           unsigned* d = g_w4_diag + (blockIdx.x * 4 + w) * 4;
-          d[0] += o0; d[1] = d[1] > o1 ? d[1] : o1; d[2] += o2; d[3] += 1;
+          d[0] += o0; d[1] += o1; d[2] += o2; d[3] += 1;
+          unsigned* e2 = g_w4_diag + 256 * 4 * 4 + (blockIdx.x * 4 + w) * 2;       // gap between two tiles' loops (epilogue + set-up)
+          if (sidx != 0) e2[0] += o3 - e2[1];
+          e2[1] = o4;
         }
+        w4_diag_end = o4;
       }
 #endif
     } else if constexpr (A_KC) {
@@ -1219,18 +1388,45 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     sidx += (unsigned)nk;
     // epilogue: the accumulators leave a[0:255] in two halves of 64 columns = one wave tile of the 8-wave form each
     const int mw = m0 + wm * 128;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      f32x4 acc[8][4];
-      if (c == 0) w4_read_acc_c0(acc);
-      else w4_read_acc_c1(acc);
-      const int vw = 2 * wn + c;                    // the 8-wave form's wave column
-      if constexpr (EK == 4) gemm_epilogue_rope<8, 4>(g, acc, mw, n0, vw);
-      else if constexpr (EK == 3) gemm_epilogue_swiglu<8, 4>(g, acc, mw, n0 + vw * 32);
-      else if constexpr (EK == 2) gemm_epilogue_ek2<8, 4>(g, acc, mw, n0 + vw * 64);
-      else if constexpr (EK == 0) gemm_epilogue_ek0<8, 4>(g, acc, mw, n0 + vw * 64);
-      else gemm_epilogue_plain<8, 4, false, true>(g, acc, mw, n0 + vw * 64);
+    // Everything the epilogue derives from the lane index (row / column offsets, bounds, bias values) would be hoisted out of the
+    // tile loop and carried THROUGH the asm statement, where only v0-v91 exist: it came back from scratch, and every scratch reload's
+    // s_waitcnt vmcnt(0) also waited out the stores issued before it -- ~21 000 cycles per tile (tools/w4_stamps.py).  An opaque copy
+    // of the lane index made here keeps those values on this side of the K loop.
+    int lane = l;
+    asm volatile("" : "+v"(lane));
+    const int emode = (g.epi & MM_EPI_RESIDUAL) ? ((g.epi & MM_EPI_ACCUMULATE) ? 3 : 1) : ((g.epi & MM_EPI_ACCUMULATE) ? 2 : 0);   // wave-uniform
+    if (EK == 0 && g.rowmajor && emode != 3) {
+      char* xp = smem + 131072 + w * 8192;
+      if (emode == 0) w4_epilogue_rowmajor<0>(g, xp, mw, n0 + wn * 128, lane);
+      else if (emode == 1) w4_epilogue_rowmajor<1>(g, xp, mw, n0 + wn * 128, lane);
+      else w4_epilogue_rowmajor<2>(g, xp, mw, n0 + wn * 128, lane);
+    } else {
+      auto chunk = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        f32x4 acc[8][4];
+        if constexpr (c == 0) w4_read_acc_c0(acc);
+        else w4_read_acc_c1(acc);
+        const int vw = 2 * wn + c;                  // the 8-wave form's wave column
+        if constexpr (EK == 4) gemm_epilogue_rope<8, 4>(g, acc, mw, n0, vw, lane);
+        else if constexpr (EK == 3) gemm_epilogue_swiglu<8, 4>(g, acc, mw, n0 + vw * 32, lane);
+        else if constexpr (EK == 2) gemm_epilogue_ek2<8, 4>(g, acc, mw, n0 + vw * 64, lane);
+        else if constexpr (EK == 0) {
+          if (!g.stream_epi || emode == 3 || (g.N & 3)) gemm_epilogue_ek0<8, 4>(g, acc, mw, n0 + vw * 64, lane);      // (ragged N: its scalar tail)
+          else if (emode == 0) gemm_epilogue_plain_stream<8, 4, 0>(g, acc, mw, n0 + vw * 64, lane);
+          else if (emode == 1) gemm_epilogue_plain_stream<8, 4, 1>(g, acc, mw, n0 + vw * 64, lane);
+          else gemm_epilogue_plain_stream<8, 4, 2>(g, acc, mw, n0 + vw * 64, lane);
+        } else gemm_epilogue_plain<8, 4, false, true>(g, acc, mw, n0 + vw * 64, lane);
+      };
+      chunk(std::integral_constant<int, 0>{});
+      chunk(std::integral_constant<int, 1>{});
     }
+#ifdef MM_W4_DIAG
+    if constexpr (SCHED == 121) {        // cycles from the loop's end to the last epilogue instruction issued (the rest of the gap = waiting)
+      unsigned long long tnow;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+      if (l == 0 && blockIdx.x < 256) g_w4_diag[256 * 4 * 4 + 256 * 4 * 2 + blockIdx.x * 4 + w] += (unsigned)tnow - w4_diag_end;
+    }
+#endif
     tile = next;
     m0 = nm0;
     n0 = nn0;
@@ -1741,6 +1937,9 @@ static int small_variant(int M, int N, int K) {
 }
 static int g_opt_epi_pipe = 1;      // pipelined, branch-free epilogue of the plain / SwiGLU-backward LDS-DMA kernels
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
+static int g_opt_w4_stream = 1;     // 4-wave kernel: wait-free plain epilogue (0 = gemm_epilogue_plain_pipe, A/B)
+static int g_opt_w4_stagger = 0;    // experiment: see GemmArgs::stagger
+static int g_opt_w4_rowmajor = 1;   // 4-wave kernel: row-major (LDS-transposed, 16-byte) plain epilogue; 0 = the accumulator-layout epilogue (A/B)
 static int g_opt_w4 = [] { const char* e = getenv("MM_GEMM_W4"); return e ? atoi(e) : 1; }();            // (MM_GEMM_W4=0: A/B at step level) NT / NN 256x256 tiles on the 4-wave hand-scheduled kernel (gemm_bf16_w4_kernel); 0 = the 8-wave kernel (A/B)
 
 extern "C" int mm_attn_set_issue_waves(int v);
@@ -1750,9 +1949,9 @@ extern int g_adamw_blocks;    // mm_optim.hip
 
 #ifdef MM_W4_DIAG
 extern "C" int mm_w4_diag_read(unsigned* out, int reset) {      // diag builds only (not in the ABI header): 256 x 4 x 4 words
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_diag), sizeof(unsigned) * 256 * 4 * 4) != hipSuccess) return MM_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_diag), sizeof(unsigned) * 256 * 4 * 7) != hipSuccess) return MM_ERR_LAUNCH;
   if (reset) {
-    static unsigned zeros[256 * 4 * 4];
+    static unsigned zeros[256 * 4 * 7];
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4_diag), zeros, sizeof(zeros)) != hipSuccess) return MM_ERR_LAUNCH;
   }
   return MM_OK;
@@ -1773,6 +1972,9 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_persist")) { g_opt_persist = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_epi_pipe")) { g_opt_epi_pipe = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_rowmajor")) { g_opt_w4_rowmajor = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_stream")) { g_opt_w4_stream = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_stagger")) { if (value < 0) return MM_ERR_ARG; g_opt_w4_stagger = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4")) { if (value < 0) return MM_ERR_ARG; g_opt_w4 = value; return MM_OK; }      // 0 off, 1 the shipped schedule, n > 1: gen_gemm_w4.py SCHEDS
   if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 6) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
   return MM_ERR_ARG;
@@ -1790,6 +1992,7 @@ extern "C" int mm_get_option(const char* name, int* value) {
   if (!strcmp(name, "gemm_epi_pipe")) { *value = g_opt_epi_pipe; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { *value = g_opt_issue_waves; return MM_OK; }
   if (!strcmp(name, "gemm_w4")) { *value = g_opt_w4; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_rowmajor")) { *value = g_opt_w4_rowmajor; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { *value = g_opt_kernel; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -2079,6 +2282,12 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       if (g_opt_w4 && variant == 2 && (K & 63) == 0 && K >= 192 && !g.ss && !acts && !tail4) {
         const int64_t nb4 = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
         dim3 grid4((unsigned)nb4), block4(256);
+        const size_t lds = 160 * 1024;                  // the ring (128 KB) + 8 KB per wave for the row-major epilogue's transposition
+        g.stagger = g_opt_w4_stagger;
+        g.stream_epi = g_opt_w4_stream;
+        g.rowmajor = g_opt_w4_rowmajor && (N & 7) == 0 && (ldc & 7) == 0 && mm_aligned16(C) &&
+                     (!(epilogue & MM_EPI_RESIDUAL) || ((ldr & 7) == 0 && mm_aligned16(g.residual))) &&
+                     (!(epilogue & MM_EPI_BIAS) || mm_aligned16(g.bias));
 #define MM_LAUNCH_W4(AKC, BKC, EK, SCHED)                                                                                    \
   do {                                                                                                                   \
     auto kfn = gemm_bf16_w4_kernel<AKC, BKC, EK, SCHED>;                                                                     \

@@ -10,7 +10,7 @@ from multimeditron_amd._lib import lib
 L = lib()
 g = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *s: (torch.rand(*s, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
-buf = (ctypes.c_uint * (256 * 4 * 4))()
+buf = (ctypes.c_uint * (256 * 4 * 7))()
 for M, N, Kd in ((8192, 4096, 4096), (8192, 4096, 14336), (8192, 28672, 4096)):
     a, b = r(M, Kd), r(N, Kd)
     c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
@@ -22,12 +22,16 @@ for M, N, Kd in ((8192, 4096, 4096), (8192, 4096, 14336), (8192, 28672, 4096)):
     K.gemm(0, a, b, M, N, Kd, out=c)
     torch.cuda.synchronize()
     assert L.mm_w4_diag_read(buf, 1) == 0
-    t = torch.tensor(list(buf), dtype=torch.float64).view(256, 4, 4)
+    allw = torch.tensor(list(buf), dtype=torch.float64)
+    t = allw[:256 * 16].view(256, 4, 4)
+    gap = allw[256 * 16:256 * 24].view(256, 4, 2)[:, :, 0]
+    epi = allw[256 * 24:].view(256, 4)
     nk = Kd // 64
     tiles = t[:, :, 3]
     wait, mx, loop = t[:, :, 0], t[:, :, 1], t[:, :, 2]
     print(f"NT M={M} N={N} K={Kd}: tiles/WG {tiles.mean():.2f}; loop cycles per K-step {float((loop / tiles / nk).mean()):.0f} (ideal 2048); "
           f"barrier cycles per K-step: mean {float((wait / tiles / nk).mean()):.0f}, by wave {[round(float((wait[:, w] / tiles[:, w] / nk).mean())) for w in range(4)]}, "
-          f"max single wait {float(mx.max()):.0f}, min over waves per WG {float((wait / tiles / nk).min(dim=1).values.mean()):.0f}", flush=True)
+          f"first P of a tile {float((mx / tiles).mean()):.0f} cycles; between two tiles' loops {float((gap / (tiles - 1).clamp(min=1)).mean()):.0f} cycles "
+          f"(a tile's loop {float((loop / tiles).mean()):.0f}); loop end -> last epilogue instruction issued {float((epi / tiles).mean()):.0f}", flush=True)
     for wg in (0, 1, 100):
         print(f"   WG {wg}: wait/K-step by wave {[round(float(wait[wg, w] / tiles[wg, w] / nk)) for w in range(4)]}  loop/K-step {[round(float(loop[wg, w] / tiles[wg, w] / nk)) for w in range(4)]}")
