@@ -410,6 +410,7 @@ def main():
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ       # torchrun with one rank still rehearses the RCCL path
     if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL, also when a launcher (not launch_ranks) started us
         opts = None
         try:      # RCCL kernels on a high-priority stream: they take freed CUs ahead of queued GEMM workgroups
             opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)

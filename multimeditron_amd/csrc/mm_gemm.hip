@@ -2142,7 +2142,11 @@ static int skinny_common(int dtype, int M, int K, const void* X, int ldx, const 
   return MM_OK;
 }
 
-constexpr int64_t GEMV_X_LDS_MAX = 144 * 1024;      // x rows staged in LDS (beside 8 KB of reduction scratch)
+// x rows staged in LDS beside gemv_stream_kernel's STATIC arrays (red: 2 x 8 x 4 x 64 floats = 16 384 B, nred: 128 B) in the 160 KB of a
+// CU: 143 KB leaves 896 B of slack.  kernels.decode_fits mirrors the number; a launch that still cannot get its LDS reports
+// MM_ERR_UNSUPPORTED (the caller then takes the tiled decode step).
+constexpr int64_t GEMV_X_LDS_MAX = 143 * 1024;
+static_assert(GEMV_X_LDS_MAX + 2 * 8 * 4 * 64 * 4 + 8 * 4 * 4 <= 160 * 1024, "x + static reduction scratch must fit the CU's LDS");
 
 static bool gemv_stream_fits(int M, int K) { return (K & 7) == 0 && (int64_t)M * K * 2 <= GEMV_X_LDS_MAX; }
 
@@ -2159,7 +2163,10 @@ static int gemv_stream_launch(const SkinnyArgs& g, unsigned nblk, hipStream_t s)
 #define MM_GEMV_LAUNCH(NORM, NT)                                                                              \
   do {                                                                                                        \
     auto kfn = gemv_stream_kernel<MODE, NORM, NT>;                                                            \
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+      (void)hipGetLastError();                                                                                \
+      return MM_ERR_UNSUPPORTED;                                                                              \
+    }                                                                                                         \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, s, g, (int)nblk);                                     \
   } while (0)
   if (g.norm_w) { if (g_opt_gemv_nt) MM_GEMV_LAUNCH(true, true); else MM_GEMV_LAUNCH(true, false); }

@@ -656,9 +656,14 @@ __global__ __launch_bounds__(256) void argmax_pick_kernel(const T* logits, int V
   }
 }
 
-__global__ void argmax_unpack_kernel(const unsigned long long* packed, int rows, int64_t* out) {
+__global__ void argmax_unpack_kernel(const unsigned long long* packed, int rows, int V, int64_t* out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < rows) out[r] = (int64_t)(0x7FFFFFFF - (unsigned)(packed[r] & 0xFFFFFFFFull));
+  if (r < rows) {
+    // a row whose probabilities are all NaN (NaN logits) issues no atomic max: packed stays 0 and the index would be 0x7FFFFFFF --
+    // an out-of-range token id for the next embedding lookup.  Index 0 is what the one-launch kernel returns for such a row.
+    const unsigned idx = 0x7FFFFFFFu - (unsigned)(packed[r] & 0xFFFFFFFFull);
+    out[r] = idx < (unsigned)V ? (int64_t)idx : 0;
+  }
 }
 
 // ---------------------------------------------------------------- MoE expert fusion (image_modality_moe.py:163-205)
@@ -1008,7 +1013,7 @@ extern "C" int mm_argmax_softmax_split(int dtype, const void* logits, int rows, 
     hipLaunchKernelGGL(argmax_part_kernel<float>, grid, block, 0, s, (const float*)logits, V, ld, temperature, part, packed);
     hipLaunchKernelGGL(argmax_pick_kernel<float>, grid, block, 0, s, (const float*)logits, V, ld, temperature, (const float*)part, packed);
   }
-  hipLaunchKernelGGL(argmax_unpack_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, (const unsigned long long*)packed, rows, out);
+  hipLaunchKernelGGL(argmax_unpack_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, (const unsigned long long*)packed, rows, V, out);
   MM_CHECK_LAUNCH();
   return MM_OK;
 }

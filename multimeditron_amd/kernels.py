@@ -157,7 +157,7 @@ def gemm_rope_fwd(x2d, w, bias, rope_cols, D, cos, sin):
 # ---- decode-step fusions (M = batch <= 16 rows; see include/mm_hip.h) ----------------------------------------------------------
 def decode_fits(M, K):
     """x (M rows of K bf16) must fit the weight-streaming kernel's LDS stage."""
-    return K % 8 == 0 and M * K * 2 <= 144 * 1024
+    return K % 8 == 0 and M * K * 2 <= 143 * 1024        # csrc/mm_gemm.hip GEMV_X_LDS_MAX (160 KB minus the kernel's static reduction scratch)
 
 
 def decode_gateup_swiglu(x2d, wgu, I, norm_w=None, eps=0.0):

@@ -157,7 +157,10 @@ def _run_experts(experts, pixels, post=None):
     if (not frozen and pixels.is_cuda and not pixels.requires_grad and os.environ.get("MM_MOE_GRAPH", "1") != "0"
             and os.environ.get("MM_MOE_TRAIN_GRAPH", "1") != "0" and _graphable(experts)):
         outs = _trainable_towers(experts, pixels, tower)
-        return [post(e, o) if post is not None else o for e, o in enumerate(outs)]
+        if outs is not None:
+            return [post(e, o) if post is not None else o for e, o in enumerate(outs)]
+        # None: a forward of this pixel shape still waits for its backward (two micro-batch losses summed before .backward(), a
+        # grad-enabled evaluation in between): the graphs' saved activations are shared buffers, so THIS call takes the eager launches
     if len(experts) == 1 or not pixels.is_cuda or os.environ.get("MM_MOE_STREAMS", "1") == "0":
         return [post(e, tower(e, ex)) if post is not None else tower(e, ex) for e, ex in enumerate(experts)]
     main = torch.cuda.current_stream()
@@ -274,6 +277,11 @@ class _TowerGraphs:
         self.bwd = {}
         self.warmed = False
         self._F = F_
+        # The saved activations of the capture are SHARED buffers: a second forward before the first one's backward would overwrite
+        # what that backward reads, and a second backward of one forward would re-read buffers a later forward has refilled.
+        # `generation` counts forwards; `pending` = the generation whose backward has not run yet (None: the buffers are free).
+        self.generation = 0
+        self.pending = None
 
     def _flags(self, fresh):
         for p in self.params:
@@ -301,9 +309,15 @@ class _TowerGraphs:
                     hook(m, ())
         self.static_px.copy_(pixels)
         self.fwd.replay()
+        self.generation += 1
+        self.pending = self.generation
         return [o.detach().clone() for o in self.res]
 
-    def backward(self, grads):
+    def backward(self, grads, generation=None):
+        if generation is not None and generation != self.pending:
+            raise RuntimeError("MoE expert towers (graph replay): backward of a forward whose saved activations are gone -- it ran "
+                               "twice, or another forward of the same pixel shape ran in between (MM_MOE_TRAIN_GRAPH=0 = eager towers)")
+        self.pending = None
         F_ = self._F
         p0 = self.params[0]
         fresh = p0.grad is None or bool(getattr(p0, "_mm_fresh", False))
@@ -351,11 +365,13 @@ class _TrainableTowersFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dummy, pixels, graphs):
         ctx.graphs = graphs
-        return tuple(graphs.forward(pixels))
+        out = tuple(graphs.forward(pixels))
+        ctx.generation = graphs.generation
+        return out
 
     @staticmethod
     def backward(ctx, *grads):
-        ctx.graphs.backward(grads)
+        ctx.graphs.backward(grads, ctx.generation)
         return None, None, None
 
 
@@ -371,6 +387,8 @@ def _trainable_towers(experts, pixels, tower):
         ent = cache[key] = _TowerGraphs(experts, pixels, tower)
         if len(cache) > 8:
             cache.pop(next(iter(cache)))
+    if ent.pending is not None:
+        return None                          # its buffers hold a forward that still waits for its backward: this call runs eagerly
     p0 = ent.params[0]
     return list(_TrainableTowersFn.apply(grad_dummy(p0), pixels, ent))
 

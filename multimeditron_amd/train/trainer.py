@@ -198,8 +198,10 @@ class MultimodalTrainer:
             if hasattr(seg.param, "_mm_ss"):
                 del seg.param._mm_ss
         layers = getattr(getattr(self.model.model, "model", None), "layers", None)
-        fused = os.environ.get("MM_FUSED_NORM", "0") == "1" and self.flat.dtype == torch.bfloat16
-        early = os.environ.get("MM_EARLY_NORM", "0") == "1"
+        # (one GPU only: with a sharded optimiser step, also at world == 1 under MM_FORCE_EXCHANGE, the norm is assembled over the
+        # rank's PIECES, whose positions the sharded step indexes -- the two experiments would replace that list)
+        fused = os.environ.get("MM_FUSED_NORM", "0") == "1" and self.flat.dtype == torch.bfloat16 and not self.shard_optim
+        early = os.environ.get("MM_EARLY_NORM", "0") == "1" and not self.shard_optim
         if self.world > 1 or layers is None or not torch.cuda.is_available() or not (fused or early):
             self._alloc_norm_partials()
             return

@@ -335,11 +335,20 @@ def multimodal_embed(w, batch, meta, stages=None):
 
 
 def multimodal_forward(w, batch, meta, stages=None):
-    """Returns (logits [B,S,V], loss or None)."""
+    """Returns (logits [B,S,V], loss or None).  meta["truncation"] + meta["max_sequence_length"]: the reference's truncation branch
+    (model.py:505-514): AFTER the splice, the embeddings, labels, mask and position ids are cut to the first max_sequence_length
+    positions (S becomes that length); pinned by tests/golden/tiny_clip_llama_trunc.*."""
     e = multimodal_embed(w, batch, meta, stages)
-    h = decoder_forward(w, e, batch.get("attention_mask"), batch["position_ids"], meta["llm"], stages=stages)
+    mask, pos, labels = batch.get("attention_mask"), batch["position_ids"], batch.get("labels")
+    msl = meta.get("max_sequence_length")
+    if meta.get("truncation") and msl is not None and e.shape[1] > msl:
+        e = e[:, :msl, :]
+        labels = labels[:, :msl] if labels is not None else None
+        mask = mask[:, :msl] if mask is not None else None
+        pos = pos[:, :msl] if pos is not None else None
+    h = decoder_forward(w, e, mask, pos, meta["llm"], stages=stages)
     logits = F.linear(h, lm_head_weight(w, meta["llm"]))
-    loss = causal_lm_loss(logits, batch["labels"]) if batch.get("labels") is not None else None
+    loss = causal_lm_loss(logits, labels) if labels is not None else None
     return logits, loss
 
 

@@ -187,3 +187,67 @@ def test_c_abi_communicator_single_rank(tmp_path):
     for k in base:
         a, b = torch.from_numpy(got[k]), torch.from_numpy(base[k])
         assert float((a - b).norm() / (b.norm() + 1e-12)) < 2e-3, k
+
+
+def _rank_nccl(port, tmp, q, shard, force):
+    """ONE rank on the DEFAULT transport (torch.distributed backend "nccl" = RCCL, high-priority process-group stream), set up exactly
+    as bench.py does for the driver's multi-GPU launch."""
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MM_SHARD_OPTIM=shard)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if force:
+            os.environ["MM_FORCE_EXCHANGE"] = "1"
+        else:
+            os.environ.pop("MM_FORCE_EXCHANGE", None)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        if force:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=opts)
+        from multimeditron_amd.train.trainer import MultimodalTrainer, TrainingMode
+        from tests.model_utils import to_device
+        model, v, R = _build(os.path.join(tmp, f"nccl{shard}{int(force)}"), dtype="bfloat16")
+        tr = MultimodalTrainer(model, training_mode=TrainingMode.FULL, learning_rate=1e-3, betas=(0.9, 0.95), max_grad_norm=1.0, bucket_mb=1)
+        early = []
+        for name in ("right", "interleaved4", "left"):
+            tr.training_step(to_device(R.golden_batch(v, name)))
+            early.append(tr.exchanger.launched_early if force else 0)
+        tr.synchronize()
+        torch.cuda.synchronize()
+        sd = {k: p.detach().float().cpu().numpy() for k, p in model.named_parameters()}
+        q.put(("ok", sd, early, bool(tr.shard_optim)))
+        if force:
+            dist.barrier()
+            dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("fail: " + traceback.format_exc()[-2000:], None, None, None))
+
+
+def _run_one(tmp, shard, force):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rank_nccl, args=(_free_port(), str(tmp), q, shard, force))
+    p.start()
+    out = q.get(timeout=120)                 # a hang in a collective fails here, not at the end of the round
+    p.join(timeout=60)
+    assert out[0] == "ok", out[0]
+    return out
+
+
+@pytest.mark.parametrize("shard", ["1", "0"])
+def test_default_rccl_transport_with_one_rank(tmp_path, shard):
+    """The transport the driver's 8-GPU run takes (reference config/deepspeed.json:5-19, cli/train.py:200-201 -> here train/exchange.py over
+    torch.distributed "nccl"): in-place reduce_scatter_tensor + all_gather_into_tensor (MM_SHARD_OPTIM=1) and bucketed all_reduce (=0), on a
+    high-priority process-group stream, launched from inside backward -- run through RCCL on the GPU with ONE rank (all one GPU allows).
+    Three bf16 trainer steps must leave the parameters BIT-identical to a run that exchanges nothing, and buckets must launch early."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import numpy as np
+    ref = _run_one(tmp_path, shard, False)
+    got = _run_one(tmp_path, shard, True)
+    assert got[3] == (shard == "1")
+    assert all(e > 0 for e in got[2][1:]), got[2]                     # from step 2 on buckets leave from inside backward
+    for k in ref[1]:
+        assert np.array_equal(ref[1][k], got[1][k]), k

@@ -310,3 +310,39 @@ def test_moe_full_recipe_trainer_steps_graph_equals_eager(tmp_path, monkeypatch)
     assert res["0"][0] == res["1"][0], (res["0"][0], res["1"][0])
     assert torch.equal(res["0"][1], res["1"][1])
     assert all(l == l for l in res["0"][0])
+
+
+@pytest.mark.parametrize("pep", [False, True])
+def test_two_forwards_before_one_backward(moe, moe_pep, tmp_path, pep, monkeypatch):
+    """the trainable towers' hipGraphs share their saved activations per pixel shape.  Two forwards of the same shape whose
+    losses are summed before ONE backward must not let the second forward overwrite what the first one's backward reads: the second
+    call takes the eager launches (its graph entry is `pending`), and the result equals the all-eager run bit for bit (bf16).  A second
+    backward through a replayed forward raises instead of reading refilled buffers."""
+    meta, w, v = moe_pep if pep else moe
+    px = v["pixels"]
+    g = torch.Generator().manual_seed(9)
+    b0 = [px[i] for i in range(px.shape[0])]
+    b1 = [torch.randn_like(px[0], generator=g) for _ in range(px.shape[0])]
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MM_MOE_TRAIN_GRAPH", mode)
+        m = _build(meta, w, v, "weighted_average", torch.bfloat16, tmp_path / f"two{mode}")
+        flat = next(iter(m.parameters()))._mm_flat
+        for rep in range(2):                      # rep 0: first (eager-through-capture) backward; rep 1: replayed graphs
+            flat.attach_grads(fresh=True)
+            y0, y1 = m(b0), m(b1)
+            wgt = torch.linspace(-1, 1, y0.numel(), device=y0.device).view_as(y0)
+            ((y0.float() * wgt).sum() + (y1.float() * wgt.flip(0)).sum()).backward()
+            torch.cuda.synchronize()
+        got[mode] = (y0.detach().clone(), y1.detach().clone(), flat.grad.detach().clone())
+        if mode == "1":
+            ent = [e for k, e in m.experts._mm_graphs.items() if k[0] == "train"][0]
+            assert ent.pending is None
+            flat.attach_grads(fresh=True)
+            y = m(b0)
+            s = (y.float() * wgt).sum()
+            s.backward(retain_graph=True)
+            with pytest.raises(RuntimeError, match="saved activations are gone"):
+                s.backward()
+    for a, b in zip(got["0"], got["1"]):
+        assert torch.equal(a, b), float((a.float() - b.float()).abs().max())

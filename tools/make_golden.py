@@ -290,6 +290,26 @@ def model_fixture(name, llm_cfg, seed, long_seq=False):
 
 
 
+def trunc_fixture(name="tiny_clip_llama_trunc", seed=100, msl=40):
+    """The truncation branch of the reference's forward (model.py:505-514; the shipped MoE recipes set `truncation: true`): the model of
+    `tiny_clip_llama` (same seed -> same weights, tiny_clip_llama.weights.safetensors) with config.truncation = True and
+    max_sequence_length = msl < S.  Stored: the batch, the TRUNCATED logits, the loss and selected gradients."""
+    with tempfile.TemporaryDirectory() as tmp:
+        model = build_model(llama_cfg(), seed, tmp)
+        model.config.truncation = True
+        model.config.max_sequence_length = msl
+        out = {}
+        run_case(model, make_batch(seed + 11, 56, [[3], [2, 28]], "right"), "trunc_right", out)        # second image span 28..37 ends before msl
+        run_case(model, make_batch(seed + 12, 64, [[2, 30]], "none"), "trunc_cut_image", out)             # ... and one cut in the middle of its span
+        keep = {k: v.contiguous() for k, v in out.items() if ".act." not in k}
+        save_file(keep, os.path.join(OUT, f"{name}.vectors.safetensors"))
+        with open(os.path.join(OUT, f"{name}.meta.json"), "w") as f:
+            json.dump(dict(name=name, weights="tiny_clip_llama.weights.safetensors", max_sequence_length=msl, truncation=True,
+                           cases=sorted({k.split(".")[0] for k in keep}), transformers=transformers.__version__, torch=torch.__version__),
+                      f, indent=1, sort_keys=True)
+        print(name, "vector tensors", len(keep), {k: tuple(v.shape) for k, v in keep.items() if k.endswith("logits")})
+
+
 # ---- SigLIP plug-in (BASELINE config 5) ---------------------------------------------------------
 # The reference ships no SigLIP modality (SURVEY.md section 0, fact 9): config 5 plugs an alternate embedder in through
 # the reference's OWN plug-in protocol (BaseModalityConfig / BaseModalityProcessor / BaseModality + AutoModality.register,
@@ -766,9 +786,11 @@ def collator_fixture():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["llama", "qwen2", "llama_d128", "siglip", "moe", "moe_pep", "collator", "ckpt"]
+    which = sys.argv[1:] or ["llama", "trunc", "qwen2", "llama_d128", "siglip", "moe", "moe_pep", "collator", "ckpt"]
     if "llama" in which:
         model_fixture("tiny_clip_llama", llama_cfg(), 100)
+    if "trunc" in which:
+        trunc_fixture()
     if "qwen2" in which:
         model_fixture("tiny_clip_qwen2", qwen2_cfg(), 200)
     if "llama_d128" in which:
