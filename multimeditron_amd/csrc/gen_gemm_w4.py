@@ -52,13 +52,17 @@ class Sched:
 
     def __init__(self, sid, ra=(0, 40), tog=(44, 62), rb=(0, 44), dma0=1, dma_stride=2, book0=50, coarse=True,
                  no_dma=False, no_reads=False, no_sync=False, no_vmwait=False, no_barrier=False, oob_dma=False, diag=False,
-                 wave_shift=0, read_shift=0, stamps=False):
+                 wave_shift=0, read_shift=0, stamps=False, split=None):
         self.sid, self.ra, self.tog, self.rb, self.dma0, self.dma_stride, self.book0 = sid, ra, tog, rb, dma0, dma_stride, book0
         self.coarse, self.no_dma, self.no_reads, self.no_sync, self.diag = coarse, no_dma, no_reads, no_sync, diag
         self.no_vmwait, self.no_barrier, self.oob_dma = no_vmwait, no_barrier, oob_dma
         # wave_shift / read_shift > 0: FOUR copies of the K loop, one per wave; wave w's DMA pieces (fragment reads) sit wave_shift * w
         # (read_shift * w) gaps later than wave 0's, so the CU's four waves do not present their requests in the same cycles
         self.wave_shift, self.read_shift = wave_shift, read_shift
+        # split = (xgap, ygap, n_dma_in_phase_a): TWO barriers per K-step.  X (phase A, behind MFMA xgap): every wave has read all of
+        # stage(s) -> DMA(s+2) starts there, n pieces still in phase A; Y (phase B, behind MFMA ygap): every wave's DMA(s+1) has landed
+        # -> the set-0 reads of step s+1 follow.  A piece gets 105-168 MFMAs to land instead of 68-128.
+        self.split = split
         self.stamps = stamps          # s_memtime around every barrier: cycles spent at it (sum, max) and in the whole loop -> asm outputs
         self.copies = 4 if (wave_shift or read_shift) else 1
 
@@ -69,6 +73,8 @@ SCHEDS = [
     Sched(1, dma0=0, dma_stride=4),                 # shipped: a wave's 16 DMA pieces 4 MFMAs (64 cycles) apart over the whole of phase B
     Sched(2, dma0=1, dma_stride=2),                 # round-4 first cut (pieces 2 MFMAs apart): -4 % (profiles/r04_gemm_w4.md)
     Sched(3, dma0=0, dma_stride=4, coarse=False),   # counted lgkmcnt waits instead of one per K-step
+    Sched(4, dma0=2, dma_stride=4, coarse=False, ra=(0, 32), book0=20, split=(44, 20, 5), rb=(21, 53)),
+    Sched(5, dma0=2, dma_stride=4, coarse=False, ra=(0, 30), book0=16, split=(36, 28, 7), rb=(29, 57)),
     # ---- timing-only builds (-DMM_W4_DIAG, tools/build_diag.sh): each drops one ingredient of schedule 1
     Sched(111, dma0=0, dma_stride=4, no_dma=True, diag=True),
     Sched(112, dma0=0, dma_stride=4, no_reads=True, diag=True),
@@ -245,6 +251,20 @@ def gen_variant(v, sc):
             n0 += 1
             if n0 == 2:
                 g0, n0 = g0 + 1, 0
+        def dma_piece(k):
+            X, i = "AB"[k // 8], k % 8
+            d = 72 if sc.oob_dma else S_DESC[X]
+            return (("raw", f"s_add_u32 m0, s{S_DST}, {TILE_OFF[X] + i * 4096}"),
+                    ("raw", f"buffer_load_dwordx4 v{V_VOFF[X] + i}, s[{d}:{d + 3}], 0 offen lds"))
+        if sc.split:
+            xgap, ygap, na = sc.split
+            aux[xgap].append(("xbar",))
+            for k in range(na):                      # the first pieces of DMA(s+2), still in phase A
+                g = xgap + 2 + sc.dma_stride * k
+                assert g <= 63
+                m0w, ld = dma_piece(k)
+                aux[g - 1].append(m0w)
+                aux[g].append(ld)
         m = 0
         if sc.coarse and not sc.no_sync:
             e.lgkm_wait()
@@ -256,11 +276,14 @@ def gen_variant(v, sc):
                 for a in aux[m]:
                     if a[0] == "lds":
                         e.lds(a[1], a[2])
+                    elif a[0] == "xbar":
+                        e.lgkm_wait()
+                        e.raw("s_barrier")
                     else:
                         e.raw(a[1])
                 m += 1
         # ---- P
-        if not sc.no_sync:
+        if not sc.no_sync and not sc.split:
             if sc.stamps:
                 e.raw("s_memtime s[92:93]")
             if sc.no_vmwait:
@@ -284,21 +307,30 @@ def gen_variant(v, sc):
         for (f, s), g in zip(insts, [g + sc.read_shift * wv for g in spread(len(insts), *sc.rb)]):
             if not sc.no_reads:
                 aux[g].append(("lds", f, s))
-        k = 0
         pre = []
-        for X in "AB":
-            for i in range(8):
+        if sc.split:
+            xgap, ygap, na = sc.split
+            younger = na                             # DMA(s+2) pieces issued before Y: they may still be in flight there
+            for k in range(na, 16):
+                g = sc.dma0 + sc.dma_stride * (k - na)
+                assert 1 <= g <= 62
+                if g <= ygap:
+                    younger += 1
+                m0w, ld = dma_piece(k)
+                aux[g - 1].append(m0w)
+                aux[g].append(ld)
+            aux[ygap].append(("ybar", younger))
+        else:
+            for k in range(16):
                 g = sc.dma0 + sc.dma_stride * k + sc.wave_shift * wv          # the DMA's gap; M0 is written one gap earlier (a wait state)
-                m0w = ("raw", f"s_add_u32 m0, s{S_DST}, {TILE_OFF[X] + i * 4096}")
+                m0w, ld = dma_piece(k)
                 if g == 0:
                     pre.append(m0w)
                 else:
                     aux[g - 1].append(m0w)
                 if not sc.no_dma:
-                    d = 72 if sc.oob_dma else S_DESC[X]
-                    aux[g].append(("raw", f"buffer_load_dwordx4 v{V_VOFF[X] + i}, s[{d}:{d + 3}], 0 offen lds"))
-                k += 1
-        assert sc.dma0 + sc.dma_stride * 15 + sc.wave_shift * 3 <= 63
+                    aux[g].append(ld)
+        assert sc.split or sc.dma0 + sc.dma_stride * 15 + sc.wave_shift * 3 <= 63
         aux[63].append(("raw", f"s_xor_b32 s{S_DST}, s{S_DST}, {STAGE}"))      # the stage the next K-step's DMA refills
         m = 0
         for a in pre:
@@ -311,6 +343,9 @@ def gen_variant(v, sc):
                 for a in aux[m]:
                     if a[0] == "lds":
                         e.lds(a[1], a[2])
+                    elif a[0] == "ybar":
+                        e.raw(f"s_waitcnt vmcnt({a[1]})")
+                        e.raw("s_barrier")
                     else:
                         e.raw(a[1])
                 m += 1

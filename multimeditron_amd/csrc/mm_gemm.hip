@@ -860,8 +860,8 @@ __device__ __forceinline__ void dma_tile(unsigned tile, const SRsrc& rs, int ld,
 // of the hardware range check, so this form is only used for K-steps that lie wholly inside K (the ragged last step
 // goes through dma_tile, whose offsets carry the K bound).
 template <bool KC, int XR, int NW>
-__device__ __forceinline__ void dma_offsets(unsigned (&offs)[XR / (8 * NW)], int ld, int swi_I = 0) {
-  const int l = threadIdx.x & 63;
+__device__ __forceinline__ void dma_offsets(unsigned (&offs)[XR / (8 * NW)], int ld, int swi_I = 0, int lane = -1) {
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int PPW = XR / (8 * NW);
 #pragma unroll
@@ -1298,26 +1298,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   __builtin_amdgcn_s_barrier();
   dma_tile_inv<256, 4>(lds0 + 65536u, ra, offa, A_KC ? 128u : 64u * lda2);
   dma_tile_inv<256, 4>(lds0 + 65536u + 32768u, rb, offb, B_KC ? 128u : 64u * ldb2);
-  // lane parts of the fragment addresses (frag_load2's formulas with the wave's first row block; + 2048 per 16 rows in the asm)
-  const unsigned voffa0 = offa[0], voffa1 = offa[1], voffb0 = offb[0], voffb1 = offb[1];
-  const int lr = l & 15, lg = l >> 4;
-  unsigned rda_lo, rda_hi, rdb_lo, rdb_hi;
-  if constexpr (A_KC) {
-    rda_lo = (unsigned)((wm * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
-    rda_hi = (unsigned)((wm * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
-  } else {
-    const int q = lr >> 2, p = lr & 3, k = 8 * lg + q;
-    rda_lo = (unsigned)(k * 512 + p * 8);
-    rda_hi = (unsigned)(((wm * 8 + ks_swz(k)) & 15) * 32);
-  }
-  if constexpr (B_KC) {
-    rdb_lo = 32768u + (unsigned)((wn * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
-    rdb_hi = 32768u + (unsigned)((wn * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
-  } else {                                          // K-strided image: row part, and the rotated 32-byte column slot of fragment 0
-    const int q = lr >> 2, p = lr & 3, k = 8 * lg + q;
-    rdb_lo = 32768u + (unsigned)(k * 512 + p * 8);
-    rdb_hi = (unsigned)(((wn * 8 + ks_swz(k)) & 15) * 32);
-  }
+  // lane parts of the fragment addresses (frag_load2's formulas with the wave's first row block; + 2048 per 16 rows in the asm).
+  // Recomputed per tile from an opaque copy of the lane index: as loop invariants they would have to live through the asm statement,
+  // where the compiler has v0-v91 only, and came back from scratch behind an s_waitcnt vmcnt(0) that also waits out the epilogue's stores.
+  auto frag_addr = [&](int lane_, unsigned& rda_lo, unsigned& rda_hi, unsigned& rdb_lo, unsigned& rdb_hi) {
+    const int lr = lane_ & 15, lg = lane_ >> 4;
+    if constexpr (A_KC) {
+      rda_lo = (unsigned)((wm * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
+      rda_hi = (unsigned)((wm * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
+    } else {
+      const int q = lr >> 2, p = lr & 3, k = 8 * lg + q;
+      rda_lo = (unsigned)(k * 512 + p * 8);
+      rda_hi = (unsigned)(((wm * 8 + ks_swz(k)) & 15) * 32);
+    }
+    if constexpr (B_KC) {
+      rdb_lo = 32768u + (unsigned)((wn * 128 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
+      rdb_hi = 32768u + (unsigned)((wn * 128 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
+    } else {                                        // K-strided image: row part, and the rotated 32-byte column slot of fragment 0
+      const int q = lr >> 2, p = lr & 3, k = 8 * lg + q;
+      rdb_lo = 32768u + (unsigned)(k * 512 + p * 8);
+      rdb_hi = (unsigned)(((wn * 8 + ks_swz(k)) & 15) * 32);
+    }
+  };
   // wave-uniform strides between a wave's DMA pieces (piece i = 8 rows at local row 8 w + 32 i; bits 0, 1, 2 of i)
   const unsigned ta = w4_sgpr(A_KC ? 32u * lda2 : 16u * lda2);       // A is never gathered: 32 rows per piece step (K-strided: 16 k-rows)
   unsigned tb0, tb1 = 0, tb2 = 0;
@@ -1348,6 +1350,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     }
     na0 = w4_sgpr(na0); na1 = w4_sgpr(na1); na2 = w4_sgpr(na2); nb0 = w4_sgpr(nb0); nb1 = w4_sgpr(nb1); nb2 = w4_sgpr(nb2);
     const unsigned st = (sidx & 1u) * 65536u;
+    int lane_in = l;
+    asm volatile("" : "+v"(lane_in));
+    unsigned rda_lo, rda_hi, rdb_lo, rdb_hi;
+    frag_addr(lane_in, rda_lo, rda_hi, rdb_lo, rdb_hi);
+    unsigned toa[8], tob[8];                        // (the asm rebuilds pieces 1.. / 2.. from the first one or two and the strides)
+    dma_offsets<A_KC, 256, 4>(toa, g.lda, 0, lane_in);
+    dma_offsets<B_KC, 256, 4>(tob, g.ldb, swi, lane_in);
+    const unsigned voffa0 = toa[0], voffa1 = toa[1], voffb0 = tob[0], voffb1 = tob[1];
     const unsigned a0 = ra.w0, a1 = ra.w1, a2 = ra.w2, b0 = rb.w0, b1 = rb.w1, b2 = rb.w2;
     const unsigned rda0 = rda_lo + st, rda1 = A_KC ? rda_hi + st : rda_hi, rdb0 = rdb_lo + st;
     const unsigned dst = w4_sgpr(st + (unsigned)w * 1024u);
@@ -2303,9 +2313,9 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
   } while (0)
 #define MM_W4_CASE(AKC, BKC, SCHED) case SCHED: MM_LAUNCH_W4(AKC, BKC, 0, SCHED); break;
 #ifdef MM_W4_DIAG
-#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 104) MM_W4_CASE(AKC, BKC, 105) MM_W4_CASE(AKC, BKC, 111) MM_W4_CASE(AKC, BKC, 112) MM_W4_CASE(AKC, BKC, 113) MM_W4_CASE(AKC, BKC, 114) MM_W4_CASE(AKC, BKC, 115) MM_W4_CASE(AKC, BKC, 117) MM_W4_CASE(AKC, BKC, 121)
+#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5) MM_W4_CASE(AKC, BKC, 104) MM_W4_CASE(AKC, BKC, 105) MM_W4_CASE(AKC, BKC, 111) MM_W4_CASE(AKC, BKC, 112) MM_W4_CASE(AKC, BKC, 113) MM_W4_CASE(AKC, BKC, 114) MM_W4_CASE(AKC, BKC, 115) MM_W4_CASE(AKC, BKC, 117) MM_W4_CASE(AKC, BKC, 121)
 #else
-#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3)
+#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5)
 #endif
         if (g.rope_cols) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, true, 4, 1); }
         else if (g.swi_I) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, true, 3, 1); }
