@@ -1247,6 +1247,154 @@ __device__ __forceinline__ void w4_rm_half(const GemmArgs& g, char* xp, __amdgpu
   w4_rm_block<3, C, MODE>(g, xp, rc, rr, colb, bv, has_bias, l);
 }
 
+// 32 rows x 64 columns of the wave's fp32 accumulators through its 8 KB of spare LDS: out v[it][0..7] = row 8 it + (l >> 3), columns
+// 8 (l & 7) .. + 7 of the block (rows 32 IP.., columns 64 C.. of the wave tile)
+template <int IP, int C>
+__device__ __forceinline__ void w4_xpose_blk(char* xp, int l, float (&v)[4][8]) {
+  const int wr = l & 15, wq = l >> 4, r8 = l >> 3, c8 = l & 7;
+  f32x4 a[2][4];
+  w4_read_acc_blk<IP, C>(a);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int row = ii * 16 + wr, ch = jj * 4 + wq;
+      *(f32x4*)(xp + row * 256 + ((ch ^ (row & 15)) * 16)) = a[ii][jj];
+    }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + r8;
+    const f32x4 lo = *(const f32x4*)(xp + row * 256 + (((2 * c8) ^ (row & 15)) * 16));
+    const f32x4 hi = *(const f32x4*)(xp + row * 256 + (((2 * c8 + 1) ^ (row & 15)) * 16));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[it][r] = lo[r]; v[it][4 + r] = hi[r]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// SwiGLU-backward epilogue (mm_gemm_swiglu_bwd, EK == 2) of the 4-wave kernel in row-major form: per 32 x 64 block a lane reads the saved
+// gate / up pre-activations of its 8 columns (2 x 16 bytes per row) and writes d(gate), d(up) (2 x 16 bytes): a wave-wide access = 8 rows
+// x one 128-byte line, where the accumulator layout gave 16 rows x 32 bytes and four times as many instructions.  The loads of block
+// b + 1 are requested before block b's stores, so a wait for them never waits for a store.  Arithmetic of gemm_epilogue_swiglu_bwd_pipe
+// element for element: bit-identical.  Host: N (= I) % 8 == 0, 16-byte aligned C / aux rows.
+struct W4Swb { u32x4 g[4], u[4]; };
+template <int B8>
+__device__ __forceinline__ void w4_swb_request(const GemmArgs& g, __amdgpu_buffer_rsrc_t ra, int nw, int l, W4Swb& q) {
+  constexpr int IP = B8 & 3, C = B8 >> 2;
+  const int n = nw + C * 64 + (l & 7) * 8;
+  const unsigned upo = (unsigned)g.N * 2u;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = IP * 32 + it * 8 + (l >> 3);
+    const unsigned o = n < g.N ? (unsigned)(row * g.ldaux) * 2u + (unsigned)n * 2u : EPI_OOB;
+    q.g[it] = __builtin_amdgcn_raw_buffer_load_b128(ra, o, 0, 0);
+    q.u[it] = __builtin_amdgcn_raw_buffer_load_b128(ra, o == EPI_OOB ? EPI_OOB : o + upo, 0, 0);
+  }
+}
+template <int B8>
+__device__ __forceinline__ void w4_swb_block(const GemmArgs& g, char* xp, __amdgpu_buffer_rsrc_t rc, int nw, int l, const W4Swb& q) {
+  constexpr int IP = B8 & 3, C = B8 >> 2;
+  float v[4][8];
+  w4_xpose_blk<IP, C>(xp, l, v);
+  const int n = nw + C * 64 + (l & 7) * 8;
+  const unsigned upo = (unsigned)g.N * 2u;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = IP * 32 + it * 8 + (l >> 3);
+    const bf16x8 gv = __builtin_bit_cast(bf16x8, q.g[it]), uv = __builtin_bit_cast(bf16x8, q.u[it]);
+    bf16x8 dg, du;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float gf = (float)gv[r], sig = 1.0f / (1.0f + __expf(-gf));
+      const float sg = gf * sig;
+      const float dd = (float)(bf16)v[it][r];
+      du[r] = (bf16)(dd * sg);
+      dg[r] = (bf16)(dd * (float)uv[r] * (sig * (1.0f + gf * (1.0f - sig))));
+    }
+    const unsigned o = n < g.N ? (unsigned)(row * g.ldc) * 2u + (unsigned)n * 2u : EPI_OOB;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dg), rc, o, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, du), rc, o == EPI_OOB ? EPI_OOB : o + upo, 0, 0);
+  }
+}
+__device__ __forceinline__ void w4_epilogue_swiglu_bwd_rowmajor(const GemmArgs& g, char* xp, int mw, int nw, int l) {
+  mw = __builtin_amdgcn_readfirstlane(mw);
+  nw = __builtin_amdgcn_readfirstlane(nw);
+  const int rows = g.M - mw;
+  auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)rows * g.ldc * 2);
+  auto ra = make_rsrc((const bf16*)g.aux + (int64_t)mw * g.ldaux, (int64_t)rows * g.ldaux * 2);
+  W4Swb q0, q1;
+  w4_swb_request<0>(g, ra, nw, l, q0);
+  w4_swb_request<1>(g, ra, nw, l, q1); w4_swb_block<0>(g, xp, rc, nw, l, q0);
+  w4_swb_request<2>(g, ra, nw, l, q0); w4_swb_block<1>(g, xp, rc, nw, l, q1);
+  w4_swb_request<3>(g, ra, nw, l, q1); w4_swb_block<2>(g, xp, rc, nw, l, q0);
+  w4_swb_request<4>(g, ra, nw, l, q0); w4_swb_block<3>(g, xp, rc, nw, l, q1);
+  w4_swb_request<5>(g, ra, nw, l, q1); w4_swb_block<4>(g, xp, rc, nw, l, q0);
+  w4_swb_request<6>(g, ra, nw, l, q0); w4_swb_block<5>(g, xp, rc, nw, l, q1);
+  w4_swb_request<7>(g, ra, nw, l, q1); w4_swb_block<6>(g, xp, rc, nw, l, q0);
+  w4_swb_block<7>(g, xp, rc, nw, l, q1);
+}
+
+// Fused gate|up epilogue (mm_gemm_swiglu_fwd, EK == 3) of the 4-wave kernel through the same transposition: of a block's 64 columns the
+// first 32 are gate pre-activations of 32 features and the last 32 the up pre-activations of the SAME features (swiglu_row); a lane
+// takes 4 features of a row -- the gate chunk and its up chunk -- and writes gate, up and silu(gate) * up as 8-byte pieces, 8 lanes = 64
+// contiguous bytes per row and output (the accumulator layout: 32 bytes, behind bounds branches).  gemm_epilogue_swiglu's arithmetic.
+template <int IP, int C>
+__device__ __forceinline__ void w4_swf_block(const GemmArgs& g, char* xp, __amdgpu_buffer_rsrc_t rgu, __amdgpu_buffer_rsrc_t ract, int fw, int l) {
+  const int wr = l & 15, wq = l >> 4, r8 = l >> 3, c8 = l & 7;
+  f32x4 a[2][4];
+  w4_read_acc_blk<IP, C>(a);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int row = ii * 16 + wr, ch = jj * 4 + wq;
+      *(f32x4*)(xp + row * 256 + ((ch ^ (row & 15)) * 16)) = a[ii][jj];
+    }
+  __builtin_amdgcn_wave_barrier();
+  const int f = fw + 4 * c8;
+  const unsigned I2 = (unsigned)g.swi_I * 2u;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + r8;
+    const f32x4 ga = *(const f32x4*)(xp + row * 256 + ((c8 ^ (row & 15)) * 16));
+    const f32x4 ua = *(const f32x4*)(xp + row * 256 + (((8 + c8) ^ (row & 15)) * 16));
+    bf16x4 gb, ub, o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gb[r] = (bf16)ga[r]; ub[r] = (bf16)ua[r]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gf = (float)gb[r];
+      const float sg = (float)(bf16)(gf / (1.0f + __expf(-gf)));     // HF: act_fn(gate) in the storage dtype, then multiply
+      o[r] = (bf16)(sg * (float)ub[r]);
+    }
+    const int grow = IP * 32 + row;
+    const unsigned og = f < g.swi_I ? (unsigned)(grow * g.ldc) * 2u + (unsigned)f * 2u : EPI_OOB;
+    const unsigned oa = f < g.swi_I ? (unsigned)(grow * g.ldc2) * 2u + (unsigned)f * 2u : EPI_OOB;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, gb), rgu, og, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ub), rgu, og == EPI_OOB ? EPI_OOB : og + I2, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ract, oa, 0, 0);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int C>
+__device__ __forceinline__ void w4_swf_half(const GemmArgs& g, char* xp, __amdgpu_buffer_rsrc_t rgu, __amdgpu_buffer_rsrc_t ract, int fw, int l) {
+  w4_swf_block<0, C>(g, xp, rgu, ract, fw, l);
+  w4_swf_block<1, C>(g, xp, rgu, ract, fw, l);
+  w4_swf_block<2, C>(g, xp, rgu, ract, fw, l);
+  w4_swf_block<3, C>(g, xp, rgu, ract, fw, l);
+}
+__device__ __forceinline__ void w4_epilogue_swiglu_fwd_rowmajor(const GemmArgs& g, char* xp, int mw, int n0, int wn, int l) {
+  mw = __builtin_amdgcn_readfirstlane(mw);
+  const int rows = g.M - mw;
+  auto rgu = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)rows * g.ldc * 2);
+  auto ract = make_rsrc((const bf16*)g.C2 + (int64_t)mw * g.ldc2, (int64_t)rows * g.ldc2 * 2);
+  w4_swf_half<0>(g, xp, rgu, ract, __builtin_amdgcn_readfirstlane(n0 + (2 * wn) * 32), l);
+  w4_swf_half<1>(g, xp, rgu, ract, __builtin_amdgcn_readfirstlane(n0 + (2 * wn + 1) * 32), l);
+}
+
 template <int MODE>
 __device__ __forceinline__ void w4_epilogue_rowmajor(const GemmArgs& g, char* xp, int mw, int nw, int l) {
   mw = __builtin_amdgcn_readfirstlane(mw);
@@ -1405,7 +1553,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     int lane = l;
     asm volatile("" : "+v"(lane));
     const int emode = (g.epi & MM_EPI_RESIDUAL) ? ((g.epi & MM_EPI_ACCUMULATE) ? 3 : 1) : ((g.epi & MM_EPI_ACCUMULATE) ? 2 : 0);   // wave-uniform
-    if (EK == 0 && g.rowmajor && emode != 3) {
+    if (EK == 3 && g.rowmajor) {
+      w4_epilogue_swiglu_fwd_rowmajor(g, smem + 131072 + w * 8192, mw, n0, wn, lane);
+    } else if (EK == 2 && g.rowmajor) {
+      w4_epilogue_swiglu_bwd_rowmajor(g, smem + 131072 + w * 8192, mw, n0 + wn * 128, lane);
+    } else if (EK == 0 && g.rowmajor && emode != 3) {
       char* xp = smem + 131072 + w * 8192;
       if (emode == 0) w4_epilogue_rowmajor<0>(g, xp, mw, n0 + wn * 128, lane);
       else if (emode == 1) w4_epilogue_rowmajor<1>(g, xp, mw, n0 + wn * 128, lane);
@@ -2304,7 +2456,9 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
         g.stream_epi = g_opt_w4_stream;
         g.rowmajor = g_opt_w4_rowmajor && (N & 7) == 0 && (ldc & 7) == 0 && mm_aligned16(C) &&
                      (!(epilogue & MM_EPI_RESIDUAL) || ((ldr & 7) == 0 && mm_aligned16(g.residual))) &&
-                     (!(epilogue & MM_EPI_BIAS) || mm_aligned16(g.bias));
+                     (!(epilogue & MM_EPI_BIAS) || mm_aligned16(g.bias)) &&
+                     (!(epilogue & MM_EPI_SWIGLU_BWD) || ((g.ldaux & 7) == 0 && mm_aligned16(g.aux)));
+        if (g.swi_I) g.rowmajor = g_opt_w4_rowmajor;       // mm_gemm_swiglu_fwd: 8-byte accesses, alignment checked at the entry point
 #define MM_LAUNCH_W4(AKC, BKC, EK, SCHED)                                                                                    \
   do {                                                                                                                   \
     auto kfn = gemm_bf16_w4_kernel<AKC, BKC, EK, SCHED>;                                                                     \

@@ -181,6 +181,43 @@ def timing(quick):
 
 
 if __name__ == "__main__":
+    if "--fused" in sys.argv:               # the fused-epilogue GEMMs of a decoder layer, 8-wave vs 4-wave kernel (option given as --opt=name:v0:v1)
+        optn = [a for a in sys.argv if a.startswith("--opt=")]
+        name, v0, v1 = (optn[0][6:].split(":") if optn else ("gemm_w4", "0", "1"))
+        v0, v1 = int(v0), int(v1)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        M, H, I = 8192, 4096, 14336
+        x, wgu = rnd(g, M, H), rnd(g, 2 * I, H) * 0.05
+        dy, wd = rnd(g, M, H), rnd(g, H, I) * 0.05
+        gu = K.gemm_swiglu_fwd(x, wgu, I)[0]
+        wq = rnd(g, 6144, H) * 0.05
+        cos, sin = torch.rand(M, 64, device="cuda", generator=g), torch.rand(M, 64, device="cuda", generator=g)
+        res = rnd(g, M, H)
+        wo = rnd(g, H, H) * 0.05
+        xi = rnd(g, M, I)
+        wdn = rnd(g, H, I) * 0.05
+        jobs = [("swiglu_fwd  NT 8192x28672x4096", 2.0 * M * 2 * I * H, lambda: K.gemm_swiglu_fwd(x, wgu, I)),
+                ("swiglu_bwd  NN 8192x14336x4096", 2.0 * M * I * H, lambda: K.gemm_swiglu_bwd(dy, wd, gu, I)),
+                ("qkv + rope  NT 8192x6144x4096", 2.0 * M * 6144 * H, lambda: K.gemm_rope_fwd(x, wq, None, 40 * 128, 128, cos, sin)),
+                ("o_proj+res  NT 8192x4096x4096", 2.0 * M * H * H, lambda: K.gemm(NT, x, wo, M, H, H, residual=res)),
+                ("down+res    NT 8192x4096x14336", 2.0 * M * H * I, lambda: K.gemm(NT, xi, wdn, M, H, I, residual=res))]
+        for label, fl, fn in jobs:
+            t = {v0: [], v1: []}
+            for rep in range(5):
+                for v in (v0, v1):
+                    set_opt(name, v)
+                    fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t[v].append(e0.elapsed_time(e1) / 3)
+            med = {v: sorted(x_)[len(x_) // 2] for v, x_ in t.items()}
+            print(f"{label:34s} {name}={v0}: {fl / med[v0] / 1e9:6.0f} TF/s ({med[v0] * 1e3:6.0f} us)   {name}={v1}: {fl / med[v1] / 1e9:6.0f} TF/s ({med[v1] * 1e3:6.0f} us)", flush=True)
+        set_opt(name, 1)
+        sys.exit(0)
     stg = [a for a in sys.argv if a.startswith("--stagger=")]
     if stg:                                 # start delay per XCD slot (cycles): 0 = off
         vals = [int(x) for x in stg[0][10:].split(",")]
