@@ -169,12 +169,13 @@ def measure_gemm_roofline(trainer, batch):
 
 
 def kernel_source_sha():
-    """sha256 over the sources of the kernel `roofline` describes (the GEMM: csrc/mm_gemm.hip and csrc/mm_common.h): identifies
+    """sha256 over the sources of the kernel `roofline` describes (the GEMM: csrc/mm_gemm.hip, csrc/mm_common.h and the generator of the 4-wave kernel's K loop, csrc/gen_gemm_w4.py): identifies
     the code a PMC pass was taken on (.git does not travel to the GPU box, so a commit id cannot be checked there).  A change to
     that kernel voids the recorded traffic; a change to an unrelated kernel or a new entry point in the ABI header does not."""
     import hashlib
     h = hashlib.sha256()
-    for fn in (os.path.join(ROOT, "multimeditron_amd", "csrc", "mm_gemm.hip"), os.path.join(ROOT, "multimeditron_amd", "csrc", "mm_common.h")):
+    for fn in (os.path.join(ROOT, "multimeditron_amd", "csrc", "mm_gemm.hip"), os.path.join(ROOT, "multimeditron_amd", "csrc", "mm_common.h"),
+               os.path.join(ROOT, "multimeditron_amd", "csrc", "gen_gemm_w4.py")):
         h.update(open(fn, "rb").read())
     return h.hexdigest()[:16]
 
@@ -539,7 +540,7 @@ def main():
                                               f"{fps:.6g} flops/sample); whole_step_* count the executed flops")
         roof = None
         if r is not None:
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_dma_kernel (NT/NN/TN; every bf16 mm_gemm launch of the step)", "achieved": round(r["achieved_tflops"], 2), "peak": PEAK_BF16_TFLOPS,
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_w4_kernel + gemm_bf16_dma_kernel (NT/NN/TN; every bf16 GEMM launch of the step: 4-wave hand-scheduled 256x256 kernel, 8-wave kernel for tails / ragged K / small tiles)", "achieved": round(r["achieved_tflops"], 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(r["achieved_tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": r["launches"], "avg_launch_ms": round(r["avg_launch_ms"], 4),
                     "flops_per_launch": r["flops_per_launch"], "gemm_ms_per_step": round(r["gemm_ms_per_step"], 2),

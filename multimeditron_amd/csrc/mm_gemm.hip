@@ -2447,7 +2447,9 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       const bool acts = (epilogue & (MM_EPI_GELU_ERF | MM_EPI_QUICK_GELU | MM_EPI_GELU_TANH)) != 0;
       // (a last round at most half full goes to the 8-wave kernel, which cuts those tiles in two: g.tail below)
       const int64_t rem4 = g_opt_persist ? nwg % ncu : 0;
-      const bool tail4 = g_opt_tail && !g.swi_I && !g.rope_cols && rem4 > 0 && 2 * rem4 <= ncu;
+      // ... unless there are 3 or more full rounds in front of it: (full + 1) rounds of this kernel then take less than (full + 1/2)
+      // rounds of the 8-wave kernel, which is ~15 % slower per round (tools/gemm_bench.py)
+      const bool tail4 = g_opt_tail && !g.swi_I && !g.rope_cols && rem4 > 0 && 2 * rem4 <= ncu && nwg / ncu < 3;
       if (g_opt_w4 && variant == 2 && (K & 63) == 0 && K >= 192 && !g.ss && !acts && !tail4) {
         const int64_t nb4 = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
         dim3 grid4((unsigned)nb4), block4(256);

@@ -34,13 +34,13 @@ print("|---|---|---|---|---|---|---|")
 for ns_m, k, util, clk, rd, wr, n in rows[:14]:
     print(f"| `{k[:70]}` | {n} | {ns_m / 1e6:.1f} | {util * 100:.1f} % | {clk:.2f} | {rd:.0f} | {wr:.0f} |")
 
-# HBM bytes per launch of the dominant kernel family (all gemm_bf16_dma_kernel instantiations): what bench.py reports as
+# HBM bytes per launch of the dominant kernel family (all gemm_bf16_w4_kernel and gemm_bf16_dma_kernel instantiations): what bench.py reports as
 # roofline.traffic.  FETCH_SIZE (KiB, x2 on gfx950) and WRITE_SIZE (KiB) come from their own passes, so each is divided
 # by its own launch count.
 import json
 fb = fl = wb = wl = 0.0
 for k, v in agg.items():
-    if "gemm_bf16_dma_kernel" not in k:
+    if "gemm_bf16_dma_kernel" not in k and "gemm_bf16_w4_kernel" not in k:
         continue
     fb += 2.0 * v.get("FETCH_SIZE", 0.0) * 1024.0
     fl += calls[(k, "FETCH_SIZE")]
@@ -50,7 +50,7 @@ if fl and wl and len(sys.argv) > 2:
     import os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from bench import kernel_source_sha
-    json.dump({"kernel_source_sha": kernel_source_sha(), "kernel": "gemm_bf16_dma_kernel (all instantiations)", "read_bytes_per_launch": fb / fl, "write_bytes_per_launch": wb / wl,
+    json.dump({"kernel_source_sha": kernel_source_sha(), "kernel": "gemm_bf16_w4_kernel + gemm_bf16_dma_kernel (all instantiations)", "read_bytes_per_launch": fb / fl, "write_bytes_per_launch": wb / wl,
                "bytes_per_launch": fb / fl + wb / wl, "launches_counted": int(fl),
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 1 "
                          "--no-cpu-baseline --no-roofline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 correction); KiB -> bytes"},

@@ -14,8 +14,8 @@ shutil.copy(os.path.join(src, "pmc_traffic.json"), os.path.join(P, f"{pre}_pmc_t
 u = json.loads(open(os.path.join(src, "bench_unprofiled.json")).read())
 pr = json.loads(open(os.path.join(src, "bench_profiled.json")).read())
 rows = list(csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))))
-tot = sum(float(r["TotalDurationNs"]) for r in rows if "gemm_bf16_dma_kernel" in r["Name"])
-n = sum(int(r["Calls"]) for r in rows if "gemm_bf16_dma_kernel" in r["Name"])
+tot = sum(float(r["TotalDurationNs"]) for r in rows if "gemm_bf16_dma_kernel" in r["Name"] or "gemm_bf16_w4_kernel" in r["Name"])
+n = sum(int(r["Calls"]) for r in rows if "gemm_bf16_dma_kernel" in r["Name"] or "gemm_bf16_w4_kernel" in r["Name"])
 ru, rp = u["roofline"], pr["roofline"]
 with open(os.path.join(P, f"{pre}_bench8b_summary.md"), "w") as f:
     f.write(f"# {pre}: rocprofv3 --kernel-trace --stats over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (tools/profile_round.sh)\n\n")
@@ -23,7 +23,7 @@ with open(os.path.join(P, f"{pre}_bench8b_summary.md"), "w") as f:
             f"{u['value']} samples/s; GEMM roofline {ru['achieved']} TFLOP/s ({ru['frac']}), whole step {ru['whole_step_achieved']} TFLOP/s "
             f"({ru['whole_step_frac']}).\n")
     f.write(f"Profiled run: {pr['ms_per_step']} ms/step; average GEMM launch {rp['avg_launch_ms'] * 1e3:.1f} us from HIP events inside bench.py; the "
-            f"same from the table below (all gemm_bf16_dma_kernel rows): {n} launches, {tot / 1e6:.1f} ms => {tot / n / 1e3:.1f} us.\n")
+            f"same from the table below (all gemm_bf16_w4_kernel + gemm_bf16_dma_kernel rows): {n} launches, {tot / 1e6:.1f} ms => {tot / n / 1e3:.1f} us.\n")
     f.write("Counts are over 5 steps (1 warm-up + 3 timed + the 1-step roofline pass); 'ms/step' = total / 5.  Kernels of different streams "
             "overlap (AdamW under the next forward, deferred wgrads beside the ViT backward), so the column sums to more than the step and "
             "the small ViT kernels show 5-10x their stand-alone duration (tools/rowwise_bench.py, tools/stream_time.py: "
