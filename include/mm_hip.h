@@ -276,7 +276,7 @@ int mm_expert_fuse(int dtype, int backward, int mode, const void* X, const float
 /* ---- MoE image modality: the core of `CrossAttention` (model/attention.py:79-96: softmax(q k^T * scale) -> attn_drop -> @ v,
  * called with the generalist's P tokens as queries over the specialists' (E-1)*P tokens, image_modality_moe.py:177-203 and
  * image_modality_moe_pep.py:216-244) for head widths the flash kernels do not tile: any D that is a multiple of 8 up to 512
- * (MM_BF16; the shipped recipes need 96 = 768/8 and 512 = 4096/8), any D for MM_F32; Nkv <= 512 (the whole score row of a
+ * (MM_BF16; the shipped recipes need 96 = 768/8 and 512 = 4096/8), any D for MM_F32; Nkv <= 1024 (the whole score row of a
  * query stays in registers: no online softmax).  q [n,Nq,H,D], k/v [n,Nkv,H,D] with element strides (image, token, head);
  * out [n,Nq,H,D] contiguous; lse [n,H,Nq] f32.  drop_p = probability of zeroing an attention weight (`attn_drop`, 0.1 in the
  * reference whenever the module trains; 0 = eval): Philox4x32-10 with key `seed` and counter (call, offset); weight (row, key)

@@ -5,7 +5,7 @@
 // Shapes of the reference's recipes (cookbook/sft/moe/*/attn/{shared,pep}): P = 49 generalist queries over (E-1)*P = 196
 // specialist keys, 8 heads of width 96 (ViT-B/32 experts, C = 768) or 512 (per-expert projection, C = 4096): neither width is
 // tiled by the flash kernels of mm_attn.hip (64 / 128), and the whole score row of a query fits a wave's registers, so this is
-// NOT a flash kernel: one pass, no online softmax, any head width that is a multiple of 8 up to 512, up to 512 keys.
+// NOT a flash kernel: one pass, no online softmax, any head width that is a multiple of 8 up to 512, up to 1024 keys (above 512: the 64-tile instantiation, which spills -- a cross-attention is too small for that to matter; round 4).
 //
 // bf16 (MFMA v_mfma_f32_16x16x32_bf16, fp32 accumulate), key-major like mm_attn.hip:
 //   S^T[key][q] = K . Q^T      A = 16 keys x 32 d and B = 32 d x 16 queries, both straight from global memory (d contiguous)
@@ -481,13 +481,13 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t n, float p, u
   }
 }
 
-int pick_nkt(int KP) { const int t = KP / 16; return t <= 4 ? 4 : (t <= 8 ? 8 : (t <= 16 ? 16 : 32)); }
+int pick_nkt(int KP) { const int t = KP / 16; return t <= 4 ? 4 : (t <= 8 ? 8 : (t <= 16 ? 16 : (t <= 32 ? 32 : 64))); }
 
 int check(int dtype, int n, int Nq, int Nkv, int H, int D, float p) {
   if (n < 0 || Nq < 0 || Nkv <= 0 || H <= 0 || D <= 0 || !(p >= 0.f && p < 1.f)) return MM_ERR_ARG;
   if (dtype != MM_BF16 && dtype != MM_F32) return MM_ERR_UNSUPPORTED;
   if (dtype == MM_BF16 && ((D & 7) || D > 512)) return MM_ERR_UNSUPPORTED;
-  if (Nkv > 512) return MM_ERR_UNSUPPORTED;
+  if (Nkv > 1024) return MM_ERR_UNSUPPORTED;      // the score row of a query lives in registers: 64 MFMA tiles of 16 keys at most
   if (dtype == MM_F32 && (int64_t)(2 * Nkv + 2 * D) * 4 > 60000) return MM_ERR_UNSUPPORTED;
   return MM_OK;
 }
@@ -536,7 +536,8 @@ extern "C" int mm_xattn_fwd(int dtype, const void* q, const void* k, const void*
     case 4: XA_LAUNCH(xattn_fwd_kernel, 4); break;
     case 8: XA_LAUNCH(xattn_fwd_kernel, 8); break;
     case 16: XA_LAUNCH(xattn_fwd_kernel, 16); break;
-    default: XA_LAUNCH(xattn_fwd_kernel, 32); break;
+    case 32: XA_LAUNCH(xattn_fwd_kernel, 32); break;
+    default: XA_LAUNCH(xattn_fwd_kernel, 64); break;
   }
   MM_CHECK_LAUNCH();
   return MM_OK;
@@ -578,7 +579,8 @@ extern "C" int mm_xattn_bwd(int dtype, const void* q, const void* k, const void*
       case 4: XA_LAUNCH(xattn_bwd_q_kernel, 4); break;
       case 8: XA_LAUNCH(xattn_bwd_q_kernel, 8); break;
       case 16: XA_LAUNCH(xattn_bwd_q_kernel, 16); break;
-      default: XA_LAUNCH(xattn_bwd_q_kernel, 32); break;
+      case 32: XA_LAUNCH(xattn_bwd_q_kernel, 32); break;
+      default: XA_LAUNCH(xattn_bwd_q_kernel, 64); break;
     }
   }
 #undef XA_LAUNCH

@@ -494,9 +494,10 @@ def attn_decode(q, k, v, key_mask, scale):
 
 # ------------------------------------------------------------------------------------------------ small cross-attention + dropout
 def xattn_supported(dtype, Nkv, D):
-    """Shapes mm_xattn_* takes: up to 512 keys; bf16 head widths that are multiples of 8 up to 512, any fp32 width whose
-    score / query rows fit the wave-per-row kernel's LDS."""
-    if Nkv > 512:
+    """Shapes mm_xattn_* takes: up to 1024 keys (a query's whole score row lives in a wave's registers: 64 MFMA tiles; above 512 keys
+    the kernel trades speed for it -- it spills -- which is fine at a cross-attention's size); bf16 head widths that are multiples of
+    8 up to 512, any fp32 width whose score / query rows fit the wave-per-row kernel's LDS."""
+    if Nkv > 1024:
         return False
     if dtype == torch.bfloat16:
         return D % 8 == 0 and D <= 512

@@ -113,15 +113,16 @@ class CrossAttention(nn.Module):
         q = self.q_proj(x.reshape(n * Nq, C))
         kv = Fm.linear(context.reshape(n * Nkv, C), self._wkv, self._bkv, dummy=grad_dummy(self.k_proj.weight))
         if K.xattn_supported(x.dtype, Nkv, d):
-            # the one-pass kernel: any head width up to 512 (the shipped recipes: 768 / 8 = 96 and 4096 / 8 = 512), dropout inside
+            # the one-pass kernel: any head width up to 512 (the shipped recipes: 768 / 8 = 96 and 4096 / 8 = 512), up to 1024 keys, dropout inside
             o = Fm.cross_attention(q, kv, n, Nq, Nkv, h, d, self.scale, drop)
         else:
-            # more than 512 keys: the flash kernels, narrower heads zero-padded to 64 / 128 as the SigLIP tower's are
+            # more than 1024 keys: the flash kernels, narrower heads zero-padded to 64 / 128 as the SigLIP tower's are
             if drop > 0.0 and not getattr(CrossAttention, "_warned_no_attn_drop", False):
                 import warnings
-                CrossAttention._warned_no_attn_drop = True      # outside the reference's recipes (P = 49, E = 5: 196 keys); say so, once
+                CrossAttention._warned_no_attn_drop = True      # far outside the reference's recipes (P = 49, E = 5: 196 keys; four ViT-L/14
+                                                                # experts: 1024, which mm_xattn_* takes with its dropout); say so, once
                 warnings.warn(f"CrossAttention over {Nkv} keys runs on the flash kernels, which have no attention-probability dropout "
-                              f"(mm_xattn_* holds <= 512 keys per query): attn_drop = {drop} is NOT applied; proj_drop still is.")
+                              f"(mm_xattn_* holds <= 1024 keys per query): attn_drop = {drop} is NOT applied; proj_drop still is.")
             hw = Fm.attention_head_width(d, x.dtype)
             if hw != d:
                 q, kv = Fm.head_pad(q, h, d, hw), Fm.head_pad(kv, 2 * h, d, hw)

@@ -56,6 +56,9 @@ SHAPES = [  # n, Nq, Nkv, H, D
     (1, 70, 33, 3, 72),       # two query tiles, ragged keys, a head width that is no multiple of 16
     (1, 130, 500, 2, 128),    # three query tiles, the 32-tile instantiation
     (2, 5, 7, 1, 8),          # tiny
+    (1, 256, 1024, 2, 96),    # round 4: up to 1024 keys (4 ViT-L/14 experts x 256 patches) in the 64-tile instantiation, dropout inside
+    (1, 256, 1024, 1, 512),   # ... at the per-expert-projection recipe's head width
+    (1, 70, 777, 2, 96),      # ... ragged
 ]
 
 
