@@ -1,4 +1,9 @@
-"""Modality loaders + registry (reference dataset/loader/__init__.py:8-166)."""
+"""Modality loaders + registry (reference dataset/loader/__init__.py:8-166).
+
+This file is protocol glue off the hot path and RESTATES the reference's ~50-line registry almost line for line, on purpose: a loader
+written against the reference (`AutoModalityLoader.register("name")`, `BaseModalityLoader.load / merge_modality_with_sample`, the error
+strings a recipe author sees) must plug in unchanged, down to the reference's identifier spellings.  Nothing here is computed; the
+arithmetic of the path lives in csrc/."""
 from __future__ import annotations
 
 from abc import ABC, abstractmethod
