@@ -89,8 +89,12 @@ SCHEDS = [
 
 
 class Variant:
-    def __init__(self, name, a_kc, b_kc):
-        self.name, self.kc = name, {"A": a_kc, "B": b_kc}
+    """nj = 8: the 256 x 256 tile (a wave owns 128 x 128).  nj = 4: the 256 x 128 HALF tile of the last, half-empty round of a
+    persistent grid (a wave owns 128 x 64; the B tile has 128 rows / columns: a 16 KB image, 4 DMA pieces per wave)."""
+
+    def __init__(self, name, a_kc, b_kc, nj=8):
+        self.name, self.kc, self.nj = name, {"A": a_kc, "B": b_kc}, nj
+        self.nx = {"A": 8, "B": nj}                 # fragments (16-row blocks) and DMA pieces of an operand per wave
 
     # ---- LDS fragment reads: returns the instructions of fragment (X, ks, x)
     def frag_reads(self, X, ks, x):
@@ -99,14 +103,15 @@ class Variant:
             return [f"ds_read_b128 v[{dst}:{dst + 3}], v{V_RD[X] + ks} offset:{x * 2048}"]
         # [k][256 x] image rotated by k: the lane's row part and its rotated column depend on x -> one address register per x;
         # k + 32 (ks) and k + 4 (second half of the fragment) are constant byte offsets
-        return [f"ds_read_b64_tr_b16 v[{dst}:{dst + 1}], v{V_RD[X] + x} offset:{ks * 16384}",
-                f"ds_read_b64_tr_b16 v[{dst + 2}:{dst + 3}], v{V_RD[X] + x} offset:{ks * 16384 + 2048}"]
+        rowb = 64 * self.nx[X]                      # bytes per k-row of the image: 512 (256 wide) or 256 (the half tile's B)
+        return [f"ds_read_b64_tr_b16 v[{dst}:{dst + 1}], v{V_RD[X] + x} offset:{ks * 32 * rowb}",
+                f"ds_read_b64_tr_b16 v[{dst + 2}:{dst + 3}], v{V_RD[X] + x} offset:{ks * 32 * rowb + 4 * rowb}"]
 
     def read_order(self, ks):      # the first MFMA row needs A[0] and B[0..7]
-        return [("A", ks, 0)] + [("B", ks, j) for j in range(8)] + [("A", ks, i) for i in range(1, 8)]
+        return [("A", ks, 0)] + [("B", ks, j) for j in range(self.nj)] + [("A", ks, i) for i in range(1, 8)]
 
     def rd_regs(self, X):
-        return [V_RD[X], V_RD[X] + 1] if self.kc[X] else [V_RD[X] + x for x in range(8)]
+        return [V_RD[X], V_RD[X] + 1] if self.kc[X] else [V_RD[X] + x for x in range(self.nx[X])]
 
 
 class Emitter:
@@ -203,22 +208,27 @@ def gen_variant(v, sc):
             e.raw(f"v_add_u32 v{vo + 1}, {t0}, v{vo}")
             for k in range(2):
                 e.raw(f"v_add_u32 v{vo + 2 + k}, {t1}, v{vo + k}")
-            for k in range(4):
-                e.raw(f"v_add_u32 v{vo + 4 + k}, {t2}, v{vo + k}")
+            if v.nx[X] == 8:
+                for k in range(4):
+                    e.raw(f"v_add_u32 v{vo + 4 + k}, {t2}, v{vo + k}")
         else:                # two lane patterns (even / odd pieces), 16 rows between pieces of equal parity
             e.raw(f"v_mov_b32 v{vo}, %[voff{p}0]")
-            e.raw(f"v_mov_b32 v{vo + 1}, %[voff{p}1]")
-            for k in range(2, 8):
-                e.raw(f"v_add_u32 v{vo + k}, {'%[ta]' if X == 'A' else '%[tb0]'}, v{vo + k - 2}")
+            if v.nx[X] == 8:     # 256 wide: two lane patterns (even / odd pieces), 16 k-rows between pieces of equal parity
+                e.raw(f"v_mov_b32 v{vo + 1}, %[voff{p}1]")
+                for k in range(2, 8):
+                    e.raw(f"v_add_u32 v{vo + k}, {'%[ta]' if X == 'A' else '%[tb0]'}, v{vo + k - 2}")
+            else:                # 128 wide: one lane pattern, 16 k-rows between consecutive pieces
+                for k in range(1, 4):
+                    e.raw(f"v_add_u32 v{vo + k}, %[tb0], v{vo + k - 1}")
     # LDS read addresses
     for X, p in (("A", "a"), ("B", "b")):
         if v.kc[X]:
             e.raw(f"v_mov_b32 v{V_RD[X]}, %[rd{p}0]")
             e.raw(f"v_mov_b32 v{V_RD[X] + 1}, %[rd{p}1]")
         else:                # address of fragment x = row part + ((column part + 32 x) mod 512)
-            for x in range(8):
+            for x in range(v.nx[X]):
                 e.raw(f"v_add_u32 v{V_TMP}, {32 * x}, %[rd{p}1]")
-                e.raw(f"v_and_b32 v{V_TMP}, 511, v{V_TMP}")
+                e.raw(f"v_and_b32 v{V_TMP}, {64 * v.nx[X] - 1}, v{V_TMP}")
                 e.raw(f"v_add_u32 v{V_RD[X] + x}, %[rd{p}0], v{V_TMP}")
     # fragment set 0 of K-step 0 (the same reads, in the same order, as phase B issues for the following K-step)
     for f in v.read_order(0):
@@ -230,7 +240,8 @@ def gen_variant(v, sc):
         reads = v.read_order(1)
         insts = [(f, s) for f in reads for s in [v.frag_reads(*f)]]
         gaps = [g + sc.read_shift * wv for g in spread(len(insts), *sc.ra)]
-        aux = {g: [] for g in range(64)}
+        NG = 8 * v.nj                                # MFMAs (gaps) per phase
+        aux = {g: [] for g in range(NG)}
         for (f, s), g in zip(insts, gaps):
             if not sc.no_reads:
                 aux[g].append(("lds", f, s))
@@ -251,8 +262,10 @@ def gen_variant(v, sc):
             n0 += 1
             if n0 == 2:
                 g0, n0 = g0 + 1, 0
+        NP = 8 + v.nj                                # DMA pieces of a wave per K-step
+
         def dma_piece(k):
-            X, i = "AB"[k // 8], k % 8
+            X, i = ("A", k) if k < 8 else ("B", k - 8)
             d = 72 if sc.oob_dma else S_DESC[X]
             return (("raw", f"s_add_u32 m0, s{S_DST}, {TILE_OFF[X] + i * 4096}"),
                     ("raw", f"buffer_load_dwordx4 v{V_VOFF[X] + i}, s[{d}:{d + 3}], 0 offen lds"))
@@ -269,7 +282,7 @@ def gen_variant(v, sc):
         if sc.coarse and not sc.no_sync:
             e.lgkm_wait()
         for i in range(8):
-            for j in range(8):
+            for j in range(v.nj):
                 if not sc.coarse and not sc.no_reads:
                     e.need([("A", 0, i), ("B", 0, j)])
                 e.raw(mfma(i, j, 0, first))
@@ -303,7 +316,7 @@ def gen_variant(v, sc):
         # ---- phase B
         reads = v.read_order(0)
         insts = [(f, s) for f in reads for s in [v.frag_reads(*f)]]
-        aux = {g: [] for g in range(64)}
+        aux = {g: [] for g in range(NG)}
         for (f, s), g in zip(insts, [g + sc.read_shift * wv for g in spread(len(insts), *sc.rb)]):
             if not sc.no_reads:
                 aux[g].append(("lds", f, s))
@@ -311,9 +324,9 @@ def gen_variant(v, sc):
         if sc.split:
             xgap, ygap, na = sc.split
             younger = na                             # DMA(s+2) pieces issued before Y: they may still be in flight there
-            for k in range(na, 16):
+            for k in range(na, NP):
                 g = sc.dma0 + sc.dma_stride * (k - na)
-                assert 1 <= g <= 62
+                assert 1 <= g <= NG - 2
                 if g <= ygap:
                     younger += 1
                 m0w, ld = dma_piece(k)
@@ -321,7 +334,7 @@ def gen_variant(v, sc):
                 aux[g].append(ld)
             aux[ygap].append(("ybar", younger))
         else:
-            for k in range(16):
+            for k in range(NP):
                 g = sc.dma0 + sc.dma_stride * k + sc.wave_shift * wv          # the DMA's gap; M0 is written one gap earlier (a wait state)
                 m0w, ld = dma_piece(k)
                 if g == 0:
@@ -330,13 +343,13 @@ def gen_variant(v, sc):
                     aux[g - 1].append(m0w)
                 if not sc.no_dma:
                     aux[g].append(ld)
-        assert sc.split or sc.dma0 + sc.dma_stride * 15 + sc.wave_shift * 3 <= 63
-        aux[63].append(("raw", f"s_xor_b32 s{S_DST}, s{S_DST}, {STAGE}"))      # the stage the next K-step's DMA refills
+        assert sc.split or sc.dma0 + sc.dma_stride * (NP - 1) + sc.wave_shift * 3 <= NG - 1
+        aux[NG - 1].append(("raw", f"s_xor_b32 s{S_DST}, s{S_DST}, {STAGE}"))      # the stage the next K-step's DMA refills
         m = 0
         for a in pre:
             e.raw(a[1])
         for i in range(8):
-            for j in range(8):
+            for j in range(v.nj):
                 if not sc.no_reads and sc.no_sync:
                     e.need([("A", 1, i), ("B", 1, j)])
                 e.raw(mfma(i, j, 1, False))
@@ -395,7 +408,7 @@ def operands(v):
     """(name, constraint) of the asm inputs, in the order the kernel passes them"""
     ops = []
     for X, p in (("A", "a"), ("B", "b")):
-        ops += [(f"voff{p}0", "v")] + ([] if v.kc[X] else [(f"voff{p}1", "v")])
+        ops += [(f"voff{p}0", "v")] + ([] if (v.kc[X] or v.nx[X] == 4) else [(f"voff{p}1", "v")])
         ops += [(f"rd{p}0", "v"), (f"rd{p}1", "v")]
     for p in ("a", "b", "na", "nb"):
         ops += [(f"{p}{q}", "s") for q in range(3)]
@@ -441,6 +454,20 @@ def main():
                 out.append(f"  {'if' if first else 'else if'} constexpr (SCHED == {sc.sid}) asm volatile(MM_W4_ASM_{v.name}_S{sc.sid} : : MM_W4_INPUTS_{v.name}(__VA_ARGS__) : MM_W4_CLOBBERS); \\")
                 first = False
             out.append("  else { }")
+        out.append("")
+    # the half tile (one schedule): 32 MFMAs per phase, 12 DMA pieces per wave and K-step
+    half = Sched(1, ra=(0, 20), tog=(22, 31), rb=(0, 22), dma0=0, dma_stride=2, book0=12)
+    for v in (Variant("NT_H", True, True, 4), Variant("NN_H", True, False, 4), Variant("TN_H", False, False, 4)):
+        body = gen_variant(v, half)
+        nm = sum(1 for s in body if s.startswith("v_mfma"))
+        out.append(f"// {v.name} (256 x 128 half tile): {len(body)} instructions, {nm} MFMAs")
+        out.append(f"#define MM_W4_ASM_{v.name} \\")
+        for s in body:
+            out.append(f'  "{s}\\n\\t" \\')
+        out.append('  ""')
+        ops = operands(v)
+        out.append(f"#define MM_W4_INPUTS_{v.name}(" + ", ".join("p_" + n for n, _ in ops) + ") \\")
+        out.append("  " + ", ".join(f'[{n}] "{c}"(p_{n})' for n, c in ops))
         out.append("")
     # accumulator read-out for the epilogues.  w4_read_acc_c{c}: columns 64c .. 64c+63 of the wave's 128 (acc[i][4c + jj]), the
     # 8-wave form's wave tile; w4_read_acc_b{ip}{c}: rows 32 ip .. 32 ip + 31 of that (two row blocks) for the row-major epilogue

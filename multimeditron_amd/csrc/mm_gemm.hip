@@ -1418,12 +1418,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1;
-  const int nk = g.K / G_BK;
+  const int nk = (g.K + G_BK - 1) / G_BK;          // a ragged last K-step: K-strided operands only (TN) -- rows >= K lie beyond the running
+                                                    // descriptor's num_records and read as zeros; the host sends ragged NT / NN elsewhere
   const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
   if (lds0 != 0) __builtin_trap();                  // the ring's stage bit (0x10000) is flipped by XOR on absolute LDS addresses
-  const int total = g.nbm * g.nbn;
+  const int total_all = g.nbm * g.nbn;
+  const int total = total_all - g.tail;             // full tiles; the last g.tail tiles are cut into 256 x 128 halves below (EK == 0)
   int tile = blockIdx.x;
-  if (tile >= total) return;
+  if (tile >= total && !(g.tail > 0 && (int)blockIdx.x < 2 * g.tail)) return;
   const int swi = (EK == 3) ? g.swi_I : (EK == 4 ? -1 : 0);       // B-row gather of the fused gate|up / RoPE tiles (gather_row)
   const int nstep = swi > 0 ? 128 : 256;
   if (g.stagger > 0) {
@@ -1440,12 +1442,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   dma_offsets<B_KC, 256, 4>(offb, g.ldb, swi);
   const unsigned lda2 = (unsigned)g.lda * 2u, ldb2 = (unsigned)g.ldb * 2u;
   // K-steps 0 and 1 of the first tile; from here on every tile's asm statement issues K-steps 2.. and the next tile's 0 and 1
-  dma_tile_inv<256, 4>(lds0, ra, offa, 0u);
-  dma_tile_inv<256, 4>(lds0 + 32768u, rb, offb, 0u);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  dma_tile_inv<256, 4>(lds0 + 65536u, ra, offa, A_KC ? 128u : 64u * lda2);
-  dma_tile_inv<256, 4>(lds0 + 65536u + 32768u, rb, offb, B_KC ? 128u : 64u * ldb2);
+  if (tile < total) {
+    dma_tile_inv<256, 4>(lds0, ra, offa, 0u);
+    dma_tile_inv<256, 4>(lds0 + 32768u, rb, offb, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma_tile_inv<256, 4>(lds0 + 65536u, ra, offa, A_KC ? 128u : 64u * lda2);
+    dma_tile_inv<256, 4>(lds0 + 65536u + 32768u, rb, offb, B_KC ? 128u : 64u * ldb2);
+  }
   // lane parts of the fragment addresses (frag_load2's formulas with the wave's first row block; + 2048 per 16 rows in the asm).
   // Recomputed per tile from an opaque copy of the lane index: as loop invariants they would have to live through the asm statement,
   // where the compiler has v0-v91 only, and came back from scratch behind an s_waitcnt vmcnt(0) that also waits out the epilogue's stores.
@@ -1598,6 +1602,73 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (empty) DMAs issued for a tile that does not exist
+  // ---- the half-tile round (wave quantisation, as in the 8-wave kernel): when the last round of the persistent grid is at most half
+  // full its tiles are cut into two 256 x 128 halves handed to workgroups 0 .. 2 tail - 1.  Same A tile, a B tile of 128 rows / columns
+  // (a 16 KB image, 4 DMA pieces per wave), a wave owns 128 x 64: the MM_W4_ASM_*_H loop; same products in the same K order.
+  if constexpr (EK == 0) {
+    if (g.tail > 0 && (int)blockIdx.x < 2 * g.tail) {
+      int hm, hn;
+      block_to_tile(total + ((int)blockIdx.x >> 1), g.nbm, g.nbn, hm, hn);
+      const int hm0 = hm * 256, hn0 = hn * 256 + ((int)blockIdx.x & 1) * 128;
+      const SRsrc ha = tile_rsrc<A_KC>(A, g.lda, hm0, g.M, g.K);
+      const SRsrc hb = tile_rsrc<B_KC>(B, g.ldb, hn0, g.N, g.K);
+      int lane_in = l;                                // (opaque: nothing of this section lives through the main loop's asm statements)
+      asm volatile("" : "+v"(lane_in));
+      unsigned toa[8], tob[4];
+      dma_offsets<A_KC, 256, 4>(toa, g.lda, 0, lane_in);
+      dma_offsets<B_KC, 128, 4>(tob, g.ldb, 0, lane_in);
+      __builtin_amdgcn_s_barrier();                   // every wave has left the ring of the last full tile
+      dma_tile_inv<256, 4>(lds0, ha, toa, 0u);
+      dma_tile_inv<128, 4>(lds0 + 32768u, hb, tob, 0u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      dma_tile_inv<256, 4>(lds0 + 65536u, ha, toa, A_KC ? 128u : 64u * lda2);
+      dma_tile_inv<128, 4>(lds0 + 65536u + 32768u, hb, tob, B_KC ? 128u : 64u * ldb2);
+      unsigned rda_lo, rda_hi, rdb_lo, rdb_hi;
+      frag_addr(lane_in, rda_lo, rda_hi, rdb_lo, rdb_hi);
+      const int lr = lane_in & 15, lg = lane_in >> 4;
+      if constexpr (B_KC) {                           // the wave's 64 rows of the 128-row B image
+        rdb_lo = 32768u + (unsigned)((wn * 64 + lr) * 128 + (((0 + lg) ^ kc_swz(lr)) * 16));
+        rdb_hi = 32768u + (unsigned)((wn * 64 + lr) * 128 + (((4 + lg) ^ kc_swz(lr)) * 16));
+      } else {                                        // [k][128 x] image: 256 bytes per k-row, 8 column slots of 32 bytes
+        const int q = lr >> 2, p = lr & 3, k = 8 * lg + q;
+        rdb_lo = 32768u + (unsigned)(k * 256 + p * 8);
+        rdb_hi = (unsigned)(((wn * 4 + ks_swz(k)) & 7) * 32);
+      }
+      const unsigned voffa0 = toa[0], voffa1 = toa[1], voffb0 = tob[0];
+      const unsigned a0 = ha.w0, a1 = ha.w1, a2 = ha.w2, b0 = hb.w0, b1 = hb.w1, b2 = hb.w2;
+      const unsigned z = w4_sgpr(0u);
+      const unsigned rda0 = rda_lo, rda1 = rda_hi, rdb0 = rdb_lo, rdb1 = rdb_hi;      // stage 0
+      const unsigned dst = w4_sgpr((unsigned)w * 1024u);
+      const unsigned tbh0 = B_KC ? w4_sgpr(32u * ldb2) : w4_sgpr(16u * ldb2), tbh1 = w4_sgpr(64u * ldb2);
+      if constexpr (B_KC)
+        asm volatile(MM_W4_ASM_NT_H : : MM_W4_INPUTS_NT_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, tbh1, tbh1, nk_s, dst, wv_s) : MM_W4_CLOBBERS);
+      else if constexpr (A_KC)
+        asm volatile(MM_W4_ASM_NN_H : : MM_W4_INPUTS_NN_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s) : MM_W4_CLOBBERS);
+      else
+        asm volatile(MM_W4_ASM_TN_H : : MM_W4_INPUTS_TN_H(voffa0, voffa1, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s) : MM_W4_CLOBBERS);
+      int lane = l;
+      asm volatile("" : "+v"(lane));
+      const int mw = hm0 + wm * 128, nw = hn0 + wn * 64;
+      const int emode = (g.epi & MM_EPI_RESIDUAL) ? ((g.epi & MM_EPI_ACCUMULATE) ? 3 : 1) : ((g.epi & MM_EPI_ACCUMULATE) ? 2 : 0);
+      if (g.rowmajor && emode != 3) {
+        char* xp = smem + 131072 + w * 8192;
+        const int mwu = __builtin_amdgcn_readfirstlane(mw), nwu = __builtin_amdgcn_readfirstlane(nw);
+        const bool has_bias = (g.epi & MM_EPI_BIAS) != 0;
+        const int rows = g.M - mwu;
+        auto rc = make_rsrc((const bf16*)g.C + (int64_t)mwu * g.ldc, (int64_t)rows * g.ldc * 2);
+        auto rr = emode == 1 ? make_rsrc((const bf16*)g.residual + (int64_t)mwu * g.ldr, (int64_t)rows * g.ldr * 2) : rc;
+        if (emode == 0) w4_rm_half<0, 0>(g, xp, rc, rr, nwu, has_bias, lane);
+        else if (emode == 1) w4_rm_half<0, 1>(g, xp, rc, rr, nwu, has_bias, lane);
+        else w4_rm_half<0, 2>(g, xp, rc, rr, nwu, has_bias, lane);
+      } else {
+        f32x4 acc[8][4];
+        w4_read_acc_c0(acc);
+        gemm_epilogue_ek0<8, 4>(g, acc, mw, nw, lane);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2445,13 +2516,15 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       int64_t nblk = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
       // NT / NN 256x256 tiles: the 4-wave kernel (A K-contiguous, whole K-steps, the epilogue kinds it instantiates)
       const bool acts = (epilogue & (MM_EPI_GELU_ERF | MM_EPI_QUICK_GELU | MM_EPI_GELU_TANH)) != 0;
-      // (a last round at most half full goes to the 8-wave kernel, which cuts those tiles in two: g.tail below)
+      // (a last round at most half full: its tiles are cut into 256 x 128 halves, g.tail -- plain epilogue kinds only)
       const int64_t rem4 = g_opt_persist ? nwg % ncu : 0;
-      // ... unless there are 3 or more full rounds in front of it: (full + 1) rounds of this kernel then take less than (full + 1/2)
-      // rounds of the 8-wave kernel, which is ~15 % slower per round (tools/gemm_bench.py)
-      const bool tail4 = g_opt_tail && !g.swi_I && !g.rope_cols && rem4 > 0 && 2 * rem4 <= ncu && nwg / ncu < 3;
-      if (g_opt_w4 && variant == 2 && (K & 63) == 0 && K >= 192 && !g.ss && !acts && !tail4) {
-        const int64_t nb4 = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
+      const bool tail4 = g_opt_tail && !g.swi_I && !g.rope_cols && !(epilogue & MM_EPI_SWIGLU_BWD) && rem4 > 0 && 2 * rem4 <= ncu;
+      if (g_opt_w4 && variant == 2 && ((K & 63) == 0 || layout == MM_GEMM_TN) && K >= 192 && !g.ss && !acts) {
+        int64_t nb4 = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
+        if (tail4) {
+          g.tail = (int)rem4;
+          nb4 = nwg >= ncu ? ncu : 2 * rem4;
+        }
         dim3 grid4((unsigned)nb4), block4(256);
         const size_t lds = 160 * 1024;                  // the ring (128 KB) + 8 KB per wave for the row-major epilogue's transposition
         g.stagger = g_opt_w4_stagger;

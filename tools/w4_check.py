@@ -50,7 +50,8 @@ def check():
     set_opt("gemm_kernel", 3)             # every case on the 256x256 tile (small problems would pick a smaller one)
     cases = [(NT, 8192, 4096, 4096), (NT, 5112, 6144, 4096), (NT, 1000, 1544, 320), (NT, 2049, 4104, 1024), (NT, 8192, 4096, 14336),
              (NN, 8192, 4096, 6144), (NN, 5112, 4096, 4096), (NN, 1111, 1032, 448), (NN, 4096, 14336, 4096), (NN, 300, 520, 192),
-             (TN, 4096, 4096, 8192), (TN, 6144, 4096, 8192), (TN, 1000, 1544, 320), (TN, 4096, 14336, 8192), (TN, 777, 2056, 1024)]
+             (TN, 4096, 4096, 8192), (TN, 6144, 4096, 8192), (TN, 1000, 1544, 320), (TN, 4096, 14336, 8192), (TN, 777, 2056, 1024),
+             (TN, 4096, 4096, 5112), (TN, 6144, 4096, 5112), (TN, 520, 300, 203), (TN, 2048, 4104, 1001)]
     for lay, M, N, Kd in cases:
         a = rnd(g, M, Kd) if lay != TN else rnd(g, Kd, pad64(M))[:, :M]
         b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, pad64(N))[:, :N]
