@@ -56,6 +56,7 @@ struct GemmArgs {
   // 256x256 tile fills half 0 and zeroes half 1, the half tiles of the last round fill their own half: the slot of a value does
   // not depend on how the tiles were scheduled (persistent / one tile per workgroup, tail split or not).
   float* ss;
+  int group_m;                  // 4-wave kernel: GROUP_M of the tile order (8)
   int stream_epi;               // 4-wave kernel: the plain epilogue without waits between its stores (gemm_epilogue_plain_stream)
   int stagger;                  // 4-wave kernel: start delay in cycles per (blockIdx.x & 7) -- spreads the workgroups' epilogue bursts (experiment)
   int rowmajor;                 // 4-wave kernel: the plain epilogue in its row-major form (16-byte accesses; set by the host when alignment allows)
@@ -69,13 +70,13 @@ __device__ __forceinline__ float act_gelu_tanh(float x) {
   return 0.5f * x * (2.0f - 2.0f / (1.0f + __expf(2.0f * u)));
 }
 
-__device__ __forceinline__ void block_to_tile(int bid, int nbm, int nbn, int& pm, int& pn) {
+__device__ __forceinline__ void block_to_tile(int bid, int nbm, int nbn, int& pm, int& pn, int group_m = 8) {
   const int nwg = nbm * nbn;
   // bijective XCD remap: blocks b and b+8 share an XCD; give each XCD a contiguous chunk of tile ids
   const int xcd = bid & 7, idx = bid >> 3;
   const int q = nwg >> 3, r = nwg & 7;
   int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = group_m;       // (8 everywhere; the 4-wave kernel takes it from GemmArgs for the experiment of tools/w4_check.py --group-m)
   const int group = GROUP_M * nbn;
   const int gid = swz / group;
   const int first_m = gid * GROUP_M;
@@ -1433,7 +1434,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
   }
   int pm, pn;
-  block_to_tile(tile, g.nbm, g.nbn, pm, pn);
+  block_to_tile(tile, g.nbm, g.nbn, pm, pn, g.group_m);
   int m0 = pm * 256, n0 = pn * nstep;
   SRsrc ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
   SRsrc rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
@@ -1494,7 +1495,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     unsigned na0 = 0, na1 = 0, na2 = 0, nb0 = 0, nb1 = 0, nb2 = 0;     // no next tile: empty descriptors (every DMA lane out of range)
     if (next < total) {
       int qm, qn;
-      block_to_tile(next, g.nbm, g.nbn, qm, qn);
+      block_to_tile(next, g.nbm, g.nbn, qm, qn, g.group_m);
       nm0 = qm * 256;
       nn0 = qn * nstep;
       const SRsrc nra = tile_rsrc<A_KC>(A, g.lda, nm0, g.M, g.K), nrb = tile_rsrc<B_KC>(B, g.ldb, nn0, g.N, g.K);
@@ -1608,7 +1609,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   if constexpr (EK == 0) {
     if (g.tail > 0 && (int)blockIdx.x < 2 * g.tail) {
       int hm, hn;
-      block_to_tile(total + ((int)blockIdx.x >> 1), g.nbm, g.nbn, hm, hn);
+      block_to_tile(total + ((int)blockIdx.x >> 1), g.nbm, g.nbn, hm, hn, g.group_m);
       const int hm0 = hm * 256, hn0 = hn * 256 + ((int)blockIdx.x & 1) * 128;
       const SRsrc ha = tile_rsrc<A_KC>(A, g.lda, hm0, g.M, g.K);
       const SRsrc hb = tile_rsrc<B_KC>(B, g.ldb, hn0, g.N, g.K);
@@ -2170,6 +2171,7 @@ static int small_variant(int M, int N, int K) {
 }
 static int g_opt_epi_pipe = 1;      // pipelined, branch-free epilogue of the plain / SwiGLU-backward LDS-DMA kernels
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
+static int g_opt_w4_group_m = 8;    // experiment: GROUP_M of the 4-wave kernel's tile order
 static int g_opt_w4_stream = 1;     // 4-wave kernel: wait-free plain epilogue (0 = gemm_epilogue_plain_pipe, A/B)
 static int g_opt_w4_stagger = 0;    // experiment: see GemmArgs::stagger
 static int g_opt_w4_rowmajor = 1;   // 4-wave kernel: row-major (LDS-transposed, 16-byte) plain epilogue; 0 = the accumulator-layout epilogue (A/B)
@@ -2206,6 +2208,7 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_epi_pipe")) { g_opt_epi_pipe = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4_rowmajor")) { g_opt_w4_rowmajor = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_group_m")) { if (value < 1) return MM_ERR_ARG; g_opt_w4_group_m = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4_stream")) { g_opt_w4_stream = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_w4_stagger")) { if (value < 0) return MM_ERR_ARG; g_opt_w4_stagger = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4")) { if (value < 0) return MM_ERR_ARG; g_opt_w4 = value; return MM_OK; }      // 0 off, 1 the shipped schedule, n > 1: gen_gemm_w4.py SCHEDS
@@ -2528,6 +2531,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
         dim3 grid4((unsigned)nb4), block4(256);
         const size_t lds = 160 * 1024;                  // the ring (128 KB) + 8 KB per wave for the row-major epilogue's transposition
         g.stagger = g_opt_w4_stagger;
+        g.group_m = g_opt_w4_group_m;
         g.stream_epi = g_opt_w4_stream;
         g.rowmajor = g_opt_w4_rowmajor && (N & 7) == 0 && (ldc & 7) == 0 && mm_aligned16(C) &&
                      (!(epilogue & MM_EPI_RESIDUAL) || ((ldr & 7) == 0 && mm_aligned16(g.residual))) &&

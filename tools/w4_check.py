@@ -182,6 +182,31 @@ def timing(quick):
 
 
 if __name__ == "__main__":
+    gm = [a for a in sys.argv if a.startswith("--group-m=")]
+    if gm:                                  # GROUP_M of the tile order (L2 / MALL locality of the panels)
+        vals = [int(x) for x in gm[0][10:].split(",")]
+        T = 8192
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for lay, M, N, Kd in ((NT, T, 4096, 14336), (NT, T, 4096, 4096), (NT, T, 28672, 4096), (NN, T, 14336, 4096), (NN, T, 4096, 28672), (TN, 28672, 4096, T), (TN, 4096, 14336, T)):
+            a = rnd(g, M, Kd) if lay != TN else rnd(g, Kd, M)
+            b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, N)
+            c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            t = {}
+            for rep in range(5):
+                for v in vals:
+                    set_opt("gemm_w4_group_m", v)
+                    K.gemm(lay, a, b, M, N, Kd, out=c)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        K.gemm(lay, a, b, M, N, Kd, out=c)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t.setdefault(v, []).append(e0.elapsed_time(e1) / 3)
+            fl = 2.0 * M * N * Kd
+            print(f"{LN[lay]} M={M:6d} N={N:6d} K={Kd:6d}  " + "  ".join(f"GROUP_M {v}: {fl / sorted(x)[len(x) // 2] / 1e9:6.0f}" for v, x in t.items()), flush=True)
+        set_opt("gemm_w4_group_m", 8)
+        sys.exit(0)
     if "--fused" in sys.argv:               # the fused-epilogue GEMMs of a decoder layer, 8-wave vs 4-wave kernel (option given as --opt=name:v0:v1)
         optn = [a for a in sys.argv if a.startswith("--opt=")]
         name, v0, v1 = (optn[0][6:].split(":") if optn else ("gemm_w4", "0", "1"))
