@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Assemble profiles/rNN_other_workloads.md from what the round's gpurun calls left under gpurun_out/ (tools/other_workloads.sh, the
+"""(the GEMM evidence of round 4 has a file of its own, profiles/r04_gemm_w4.md)
+Assemble profiles/rNN_other_workloads.md from what the round's gpurun calls left under gpurun_out/ (tools/other_workloads.sh, the
 step A/B runs, the micro-benchmarks): every number in it is copied from a measured log, none typed in.
     python tools/make_other_workloads_md.py r03"""
 import glob, json, os, sys
@@ -42,19 +43,9 @@ block("generate(): prefill + decode, B = 4, S = 2048, 8B (`tools/decode_bench.py
       note="Weights streamed per token: 16.06 GB (8.03 B bf16 parameters of the decoder + lm_head); KV cache read per token: 1.07 GB.")
 block("the decode layer's kernels one by one (`tools/gemv_bench.py 4 16`: 16 layers' weights in rotation, event-timed back-to-back launches)",
       f"other_{pre}/gemv.txt")
-block("GPU-side durations of the same kernels (`rocprofv3 --kernel-trace --stats` over tools/gemv_bench.py)", "r3_exp16/prof/kernel_stats.txt")
 block("D = 128 attention forward / backward (`tools/attn_bench.py --quick`)", f"other_{pre}/attn_quick.log")
 block("row-wise kernels alone (`tools/rowwise_bench.py`)", f"other_{pre}/rowwise.log")
 block("MoE image modality, 4 x ViT-L/14 experts on 4 images (`tools/moe_bench.py 4 4`)", f"other_{pre}/moe_bench.txt")
-block("the headline's image modality alone (`tools/vit_bench.py 4` + its rocprofv3 kernel table)", "r3_vit/alone.txt")
-block("... per kernel", "r3_vit/kernel_stats.txt", tail=22)
-block("per-stream composition of one training step and the two overlap windows (`tools/stream_time.py`)", "r3_exp23/trace/stream_time.txt")
-for tag, title in (("r3_exp7", "AdamW split master / RoPE epilogue"), ("r3_exp9", "sum of squares in the wgrad epilogue (EK = 5)"),
-                   ("r3_exp11", "labelled rows: final norm + lm_head + loss"), ("r3_exp15", "labelled rows incl. the last layer's o_proj + MLP"),
-                   ("r3_exp12", "CU-masked side streams (rejected)"), ("r3_exp18", "low-priority side streams (rejected)"),
-                   ("r3_exp22", "plain NT / NN decoder GEMMs through the vendor library (opt-in MM_GEMM_LIB=1)")):
-    block(f"step A/B, same process (`tools/step_ab.py`): {title}", f"{tag}/step_ab.txt", tail=8)
-block("CU masks: where the workgroups of a masked stream run (`tools/cumask_probe.py`)", "r3_cumask.log", tail=11)
-block("weights just read by another kernel vs cold (`tools/mall_probe.py`)", "r3_mall.log", tail=4)
+block("per-stream composition of one training step and the two overlap windows (`tools/stream_time.py`)", f"other_{pre}/stream_time.txt")
 open(os.path.join(R, "profiles", f"{pre}_other_workloads.md"), "w").write("".join(out))
 print("wrote", f"profiles/{pre}_other_workloads.md", sum(len(x) for x in out), "bytes")

@@ -18,4 +18,6 @@ timeout -k 10 200 python3 tools/attn_bench.py --quick > $O/attn_quick.log 2>&1; 
 timeout -k 10 200 python3 tools/attn_bench.py --ab-q > $O/attn_ab_q.log 2>&1; tail -16 $O/attn_ab_q.log
 timeout -k 10 300 python3 tools/decode_bench.py > $O/decode.log 2>&1; tail -5 $O/decode.log
 timeout -k 10 120 python3 tools/rowwise_bench.py > $O/rowwise.log 2>&1; cat $O/rowwise.log
+timeout -k 10 300 python3 tools/gemv_bench.py 4 16 > $O/gemv.txt 2>&1; tail -12 $O/gemv.txt
+timeout -k 10 300 python3 tools/moe_bench.py 4 4 > $O/moe_bench.txt 2>&1; tail -6 $O/moe_bench.txt
 echo done

@@ -8,6 +8,10 @@ from multimeditron_amd import kernels as K
 from multimeditron_amd._lib import lib
 
 L = lib()
+for a in sys.argv[1:]:                   # e.g. gemm_w4_rowmajor=0 gemm_w4_stream=0: the round-3 pipelined epilogue
+    k, v = a.split("=")
+    assert L.mm_set_option(k.encode(), int(v)) == 0, a
+    print("option", a, flush=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *s: (torch.rand(*s, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
 buf = (ctypes.c_uint * (256 * 4 * 7))()
