@@ -492,6 +492,19 @@ def main():
             out.append("  }")
     out.append("}")
     out.append("")
+    # the same block written to LDS straight from the accumulator registers (DS instructions take AGPR data): a0..a3 = the lane's LDS byte
+    # addresses of its 16-byte chunk in rows (l & 15) for jj = 0..3 (the XOR swizzle makes them four lane patterns); rows 16.. are + 4096
+    out.append("template <int IP, int C> __device__ __forceinline__ void w4_store_acc_blk(unsigned a0, unsigned a1, unsigned a2, unsigned a3) {")
+    for ip in range(4):
+        for c in range(2):
+            lines = []
+            for ii in range(2):
+                for jj in range(4):
+                    n = ACC(2 * ip + ii, 4 * c + jj)
+                    lines.append(f"ds_write_b128 %{jj}, a[{n}:{n + 3}]" + (" offset:4096" if ii else ""))
+            out.append(f"  if constexpr (IP == {ip} && C == {c}) asm volatile(\"" + "\\n\\t".join(lines) + "\" : : \"v\"(a0), \"v\"(a1), \"v\"(a2), \"v\"(a3) : \"memory\");")
+    out.append("}")
+    out.append("")
     path = os.path.join(here, "mm_gemm_w4.inc")
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")

@@ -1182,17 +1182,13 @@ __device__ __forceinline__ void w4_rm_block(const GemmArgs& g, char* xp, __amdgp
                                             const float (&bv)[8], bool has_bias, int l) {
   constexpr bool has_res = MODE == 1, has_acc = MODE == 2;
   const int wr = l & 15, wq = l >> 4, r8 = l >> 3, c8 = l & 7;
-  f32x4 a[2][4];
-  w4_read_acc_blk<IP, C>(a);
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int row = ii * 16 + wr, ch = jj * 4 + wq;
-      *(f32x4*)(xp + row * 256 + ((ch ^ (row & 15)) * 16)) = a[ii][jj];
-    }
-  __builtin_amdgcn_wave_barrier();
+  {   // the block leaves the accumulator registers for LDS without passing through VGPRs (w4_store_acc_blk)
+    const unsigned xb = (unsigned)(uintptr_t)LDS_PTR(char, xp) + (unsigned)(wr * 256);
+    __builtin_amdgcn_wave_barrier();
+    w4_store_acc_blk<IP, C>(xb + (unsigned)(((0 + wq) ^ wr) * 16), xb + (unsigned)(((4 + wq) ^ wr) * 16), xb + (unsigned)(((8 + wq) ^ wr) * 16),
+                            xb + (unsigned)(((12 + wq) ^ wr) * 16));
+    __builtin_amdgcn_wave_barrier();
+  }
   u32x4 rbuf[4], cbuf[4];
   unsigned off[4];
 #pragma unroll
@@ -1253,17 +1249,13 @@ __device__ __forceinline__ void w4_rm_half(const GemmArgs& g, char* xp, __amdgpu
 template <int IP, int C>
 __device__ __forceinline__ void w4_xpose_blk(char* xp, int l, float (&v)[4][8]) {
   const int wr = l & 15, wq = l >> 4, r8 = l >> 3, c8 = l & 7;
-  f32x4 a[2][4];
-  w4_read_acc_blk<IP, C>(a);
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int row = ii * 16 + wr, ch = jj * 4 + wq;
-      *(f32x4*)(xp + row * 256 + ((ch ^ (row & 15)) * 16)) = a[ii][jj];
-    }
-  __builtin_amdgcn_wave_barrier();
+  {   // the block leaves the accumulator registers for LDS without passing through VGPRs (w4_store_acc_blk)
+    const unsigned xb = (unsigned)(uintptr_t)LDS_PTR(char, xp) + (unsigned)(wr * 256);
+    __builtin_amdgcn_wave_barrier();
+    w4_store_acc_blk<IP, C>(xb + (unsigned)(((0 + wq) ^ wr) * 16), xb + (unsigned)(((4 + wq) ^ wr) * 16), xb + (unsigned)(((8 + wq) ^ wr) * 16),
+                            xb + (unsigned)(((12 + wq) ^ wr) * 16));
+    __builtin_amdgcn_wave_barrier();
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + r8;
@@ -1344,17 +1336,13 @@ __device__ __forceinline__ void w4_epilogue_swiglu_bwd_rowmajor(const GemmArgs& 
 template <int IP, int C>
 __device__ __forceinline__ void w4_swf_block(const GemmArgs& g, char* xp, __amdgpu_buffer_rsrc_t rgu, __amdgpu_buffer_rsrc_t ract, int fw, int l) {
   const int wr = l & 15, wq = l >> 4, r8 = l >> 3, c8 = l & 7;
-  f32x4 a[2][4];
-  w4_read_acc_blk<IP, C>(a);
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int row = ii * 16 + wr, ch = jj * 4 + wq;
-      *(f32x4*)(xp + row * 256 + ((ch ^ (row & 15)) * 16)) = a[ii][jj];
-    }
-  __builtin_amdgcn_wave_barrier();
+  {   // the block leaves the accumulator registers for LDS without passing through VGPRs (w4_store_acc_blk)
+    const unsigned xb = (unsigned)(uintptr_t)LDS_PTR(char, xp) + (unsigned)(wr * 256);
+    __builtin_amdgcn_wave_barrier();
+    w4_store_acc_blk<IP, C>(xb + (unsigned)(((0 + wq) ^ wr) * 16), xb + (unsigned)(((4 + wq) ^ wr) * 16), xb + (unsigned)(((8 + wq) ^ wr) * 16),
+                            xb + (unsigned)(((12 + wq) ^ wr) * 16));
+    __builtin_amdgcn_wave_barrier();
+  }
   const int f = fw + 4 * c8;
   const unsigned I2 = (unsigned)g.swi_I * 2u;
 #pragma unroll
@@ -1597,10 +1585,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     tile = next;
     m0 = nm0;
     n0 = nn0;
-    if (next < total) {
-      ra = tile_rsrc<A_KC>(A, g.lda, m0, g.M, g.K);
-      rb = tile_rsrc<B_KC>(B, g.ldb, n0, g.N, g.K);
-    }
+    ra.w0 = na0; ra.w1 = na1; ra.w2 = na2;          // the next tile's descriptors were built for the prefetch: reuse them (a wave alone
+    rb.w0 = nb0; rb.w1 = nb1; rb.w2 = nb2;          // on its SIMD hides none of the ~1 500 cycles of scalar arithmetic they take)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (empty) DMAs issued for a tile that does not exist
   // ---- the half-tile round (wave quantisation, as in the 8-wave kernel): when the last round of the persistent grid is at most half
@@ -2171,6 +2157,8 @@ static int small_variant(int M, int N, int K) {
 }
 static int g_opt_epi_pipe = 1;      // pipelined, branch-free epilogue of the plain / SwiGLU-backward LDS-DMA kernels
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
+static int g_opt_w4_big = 1;        // schedule of the 4-wave kernel on wide-N / long-K NT and NN problems: 1, or 4 (split barriers: +2...+5 % on the fused
+                                    // SwiGLU GEMMs alone, 348.6 vs 352.2 ms at step level, tools/step_ab.py: off)
 static int g_opt_w4_group_m = 8;    // experiment: GROUP_M of the 4-wave kernel's tile order
 static int g_opt_w4_stream = 1;     // 4-wave kernel: wait-free plain epilogue (0 = gemm_epilogue_plain_pipe, A/B)
 static int g_opt_w4_stagger = 0;    // experiment: see GemmArgs::stagger
@@ -2208,6 +2196,7 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_epi_pipe")) { g_opt_epi_pipe = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_issue_waves")) { if (value != 4 && value != 8) return MM_ERR_ARG; g_opt_issue_waves = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4_rowmajor")) { g_opt_w4_rowmajor = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_big")) { if (value != 1 && value != 4) return MM_ERR_ARG; g_opt_w4_big = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4_group_m")) { if (value < 1) return MM_ERR_ARG; g_opt_w4_group_m = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4_stream")) { g_opt_w4_stream = value != 0; return MM_OK; }
   if (!strcmp(name, "gemm_w4_stagger")) { if (value < 0) return MM_ERR_ARG; g_opt_w4_stagger = value; return MM_OK; }
@@ -2550,11 +2539,15 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
 #else
 #define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5)
 #endif
+        // schedule: 1 everywhere (one barrier per K-step), except -- "gemm_w4_big" = 4 -- on operands that stream from beyond the
+        // Infinity Cache (a wide N or a long K): there the split-barrier schedule 4 (a DMA piece gets 105-168 MFMAs to land instead of
+        // 68-128) measured +3...+9 % (tools/w4_check.py --scheds), while on MALL-resident 4096-sized operands it costs 3 %
+        const bool big = g_opt_w4_big == 4 && g_opt_w4 == 1 && ((int64_t)N >= 14336 || (int64_t)K >= 14336);
         if (g.rope_cols) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, true, 4, 1); }
-        else if (g.swi_I) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; MM_LAUNCH_W4(true, true, 3, 1); }
-        else if (epilogue & MM_EPI_SWIGLU_BWD) { if (layout != MM_GEMM_NN) return MM_ERR_ARG; MM_LAUNCH_W4(true, false, 2, 1); }
-        else if (layout == MM_GEMM_NT) { switch (g_opt_w4) { MM_W4_CASES(true, true) default: MM_LAUNCH_W4(true, true, 0, 1); } }
-        else if (layout == MM_GEMM_NN) { switch (g_opt_w4) { MM_W4_CASES(true, false) default: MM_LAUNCH_W4(true, false, 0, 1); } }
+        else if (g.swi_I) { if (layout != MM_GEMM_NT) return MM_ERR_ARG; if (big) MM_LAUNCH_W4(true, true, 3, 4); else MM_LAUNCH_W4(true, true, 3, 1); }
+        else if (epilogue & MM_EPI_SWIGLU_BWD) { if (layout != MM_GEMM_NN) return MM_ERR_ARG; if (big) MM_LAUNCH_W4(true, false, 2, 4); else MM_LAUNCH_W4(true, false, 2, 1); }
+        else if (layout == MM_GEMM_NT) { switch (big ? 4 : g_opt_w4) { MM_W4_CASES(true, true) default: MM_LAUNCH_W4(true, true, 0, 1); } }
+        else if (layout == MM_GEMM_NN) { switch (big ? 4 : g_opt_w4) { MM_W4_CASES(true, false) default: MM_LAUNCH_W4(true, false, 0, 1); } }
         else { switch (g_opt_w4) { MM_W4_CASES(false, false) default: MM_LAUNCH_W4(false, false, 0, 1); } }
 #undef MM_W4_CASES
 #undef MM_W4_CASE
