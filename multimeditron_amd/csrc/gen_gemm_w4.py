@@ -50,7 +50,7 @@ STAGE = 0x10000
 class Sched:
     """Where the non-MFMA instructions of a K-step sit: gap g = behind the g-th MFMA of a 64-MFMA phase."""
 
-    def __init__(self, sid, ra=(0, 40), tog=(44, 62), rb=(0, 44), dma0=1, dma_stride=2, book0=50, coarse=True,
+    def __init__(self, sid, ra=(0, 40), tog=(44, 62), rb=(0, 44), dma0=1, dma_stride=2, book0=44, coarse=True,
                  no_dma=False, no_reads=False, no_sync=False, no_vmwait=False, no_barrier=False, oob_dma=False, diag=False,
                  wave_shift=0, read_shift=0, stamps=False, split=None):
         self.sid, self.ra, self.tog, self.rb, self.dma0, self.dma_stride, self.book0 = sid, ra, tog, rb, dma0, dma_stride, book0
@@ -73,8 +73,8 @@ SCHEDS = [
     Sched(1, dma0=0, dma_stride=4),                 # shipped: a wave's 16 DMA pieces 4 MFMAs (64 cycles) apart over the whole of phase B
     Sched(2, dma0=1, dma_stride=2),                 # round-4 first cut (pieces 2 MFMAs apart): -4 % (profiles/r04_gemm_w4.md)
     Sched(3, dma0=0, dma_stride=4, coarse=False),   # counted lgkmcnt waits instead of one per K-step
-    Sched(4, dma0=2, dma_stride=4, coarse=False, ra=(0, 32), book0=20, split=(44, 20, 5), rb=(21, 53)),
-    Sched(5, dma0=2, dma_stride=4, coarse=False, ra=(0, 30), book0=16, split=(36, 28, 7), rb=(29, 57)),
+    Sched(4, dma0=2, dma_stride=4, coarse=False, ra=(0, 32), book0=16, split=(44, 20, 5), rb=(21, 53)),
+    Sched(5, dma0=2, dma_stride=4, coarse=False, ra=(0, 30), book0=8, split=(36, 28, 7), rb=(29, 57)),
     # ---- timing-only builds (-DMM_W4_DIAG, tools/build_diag.sh): each drops one ingredient of schedule 1
     Sched(111, dma0=0, dma_stride=4, no_dma=True, diag=True),
     Sched(112, dma0=0, dma_stride=4, no_reads=True, diag=True),
@@ -256,12 +256,37 @@ def gen_variant(v, sc):
         for X, p in (("A", "na"), ("B", "nb")):
             for q in range(3):
                 book.append(f"s_cmov_b32 s{S_DESC[X] + q}, %[{p}{q}]")
-        g0, n0 = sc.book0, 0
-        for s in book:
-            aux[g0].append(("raw", s))
-            n0 += 1
-            if n0 == 2:
-                g0, n0 = g0 + 1, 0
+        # a ragged last K-step (K % 64 != 0): in the DMA of K-step nk - 1 the lanes of a K-CONTIGUOUS operand whose 16-byte chunk starts
+        # at or beyond K must read zeros -- bit 31 of their offset is set for that one K-step (beyond num_records: the range check
+        # returns 0) and cleared when the K range wraps to the next tile.  %[nkm1] = nk - 1, or -1 when K % 64 == 0 (never matches);
+        # %[vraga] / %[vragb] = 0x80000000 in those lanes, 0 elsewhere.  (K-strided operands need nothing: rows >= K lie beyond the
+        # running descriptor's num_records.)
+        kcops = [X for X in "AB" if v.kc[X]]
+        if kcops:
+            tag = f"{'f' if first else 'l'}{wv}"
+            book.append(f"s_cmp_eq_u32 s{S_KD}, 0")
+            book.append(f"s_cbranch_scc0 L_w4_rr{tag}_%=")
+            for X in kcops:
+                for i in range(v.nx[X]):
+                    book.append(f"v_and_b32 v{V_VOFF[X] + i}, 0x7fffffff, v{V_VOFF[X] + i}")
+            book.append(f"L_w4_rr{tag}_%=:")
+            book.append(f"s_cmp_eq_u32 s{S_KD}, %[nkm1]")
+            book.append(f"s_cbranch_scc0 L_w4_rs{tag}_%=")
+            for X in kcops:
+                for i in range(v.nx[X]):
+                    book.append(f"v_or_b32 v{V_VOFF[X] + i}, %[vrag{X.lower()}], v{V_VOFF[X] + i}")
+            book.append(f"L_w4_rs{tag}_%=:")
+        g0, n0, inblk = sc.book0, 0.0, False
+        for s in book:                               # two scalar instructions per gap; a branch, the block it skips and its label stay in
+            aux[g0].append(("raw", s))               # ONE gap (a taken branch must not jump over MFMAs)
+            if s.startswith("s_cbranch"):
+                inblk = True
+            if s.endswith(":"):
+                inblk = False
+            n0 += 1.0
+            if n0 >= 2.0 and not inblk:
+                g0, n0 = g0 + 1, 0.0
+        assert g0 < (sc.split[0] if sc.split else NG - 1), (g0, NG)
         NP = 8 + v.nj                                # DMA pieces of a wave per K-step
 
         def dma_piece(k):
@@ -415,6 +440,8 @@ def operands(v):
     ops += [("ta", "s")]
     ops += [("tb0", "s")] + ([("tb1", "s"), ("tb2", "s")] if v.kc["B"] else [])
     ops += [("nk", "s"), ("dst", "s"), ("wv", "s")]
+    if v.kc["A"] or v.kc["B"]:
+        ops += [("nkm1", "s")] + [(f"vrag{X.lower()}", "v") for X in "AB" if v.kc[X]]
     return ops
 
 
@@ -456,7 +483,7 @@ def main():
             out.append("  else { }")
         out.append("")
     # the half tile (one schedule): 32 MFMAs per phase, 12 DMA pieces per wave and K-step
-    half = Sched(1, ra=(0, 20), tog=(22, 31), rb=(0, 22), dma0=0, dma_stride=2, book0=12)
+    half = Sched(1, ra=(0, 20), tog=(22, 31), rb=(0, 22), dma0=0, dma_stride=2, book0=8)
     for v in (Variant("NT_H", True, True, 4), Variant("NN_H", True, False, 4), Variant("TN_H", False, False, 4)):
         body = gen_variant(v, half)
         nm = sum(1 for s in body if s.startswith("v_mfma"))

@@ -1407,8 +1407,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   const int l = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = w >> 1, wn = w & 1;
-  const int nk = (g.K + G_BK - 1) / G_BK;          // a ragged last K-step: K-strided operands only (TN) -- rows >= K lie beyond the running
-                                                    // descriptor's num_records and read as zeros; the host sends ragged NT / NN elsewhere
+  const int nk = (g.K + G_BK - 1) / G_BK;          // a ragged last K-step: rows >= K of a K-strided operand lie beyond the running descriptor's
+                                                    // num_records; a K-contiguous operand's lanes beyond K get bit 31 in their offsets (rag_mask)
   const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
   if (lds0 != 0) __builtin_trap();                  // the ring's stage bit (0x10000) is flipped by XOR on absolute LDS addresses
   const int total_all = g.nbm * g.nbn;
@@ -1473,6 +1473,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   }
   tb0 = w4_sgpr(tb0); tb1 = w4_sgpr(tb1); tb2 = w4_sgpr(tb2);
   const unsigned nk_s = w4_sgpr((unsigned)nk), wv_s = w4_sgpr((unsigned)w);
+  const unsigned nkm1_s = w4_sgpr((g.K & 63) ? (unsigned)(nk - 1) : 0xFFFFFFFFu);      // the ragged K-step (K-contiguous operands: gen_gemm_w4.py)
+  auto rag_mask = [&](int lane_) -> unsigned {      // bit 31 for the lanes whose source chunk of a K-contiguous row starts at or beyond K
+    const int kc = (lane_ & 7) ^ ((((w & 1) << 2) | (lane_ >> 4)) & 7);      // dma_offsets: (l & 7) ^ kc_swz(row), the same for all of a wave's pieces
+    return ((g.K & 63) && kc * 8 >= (g.K & 63)) ? 0x80000000u : 0u;
+  };
   unsigned sidx = 0;                                // K-steps streamed so far (ring position)
 #ifdef MM_W4_DIAG
   unsigned w4_diag_end = 0;
@@ -1499,19 +1504,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     dma_offsets<A_KC, 256, 4>(toa, g.lda, 0, lane_in);
     dma_offsets<B_KC, 256, 4>(tob, g.ldb, swi, lane_in);
     const unsigned voffa0 = toa[0], voffa1 = toa[1], voffb0 = tob[0], voffb1 = tob[1];
+    const unsigned vrag = rag_mask(lane_in);
     const unsigned a0 = ra.w0, a1 = ra.w1, a2 = ra.w2, b0 = rb.w0, b1 = rb.w1, b2 = rb.w2;
     const unsigned rda0 = rda_lo + st, rda1 = A_KC ? rda_hi + st : rda_hi, rdb0 = rdb_lo + st;
     const unsigned dst = w4_sgpr(st + (unsigned)w * 1024u);
     if constexpr (B_KC) {
       const unsigned rdb1 = rdb_hi + st;
-      MM_W4_RUN_NT(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s)
+      MM_W4_RUN_NT(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, nkm1_s, vrag, vrag)
 #ifdef MM_W4_DIAG
-      MM_W4_RUN_NT_DIAG(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s)
+      MM_W4_RUN_NT_DIAG(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, nkm1_s, vrag, vrag)
       if constexpr (SCHED == 121) {
         unsigned o0, o1, o2, o3, o4;
         asm volatile(MM_W4_ASM_NT_S121
                      : [o0] "=&s"(o0), [o1] "=&s"(o1), [o2] "=&s"(o2), [o3] "=&s"(o3), [o4] "=&s"(o4)
-                     : MM_W4_INPUTS_NT(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s)
+                     : MM_W4_INPUTS_NT(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, nkm1_s, vrag, vrag)
                      : MM_W4_CLOBBERS_DIAG);
         if (l == 0 && blockIdx.x < 256) {
           unsigned* d = g_w4_diag + (blockIdx.x * 4 + w) * 4;
@@ -1525,9 +1531,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
 #endif
     } else if constexpr (A_KC) {
       const unsigned rdb1 = rdb_hi;
-      MM_W4_RUN_NN(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s)
+      MM_W4_RUN_NN(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s, nkm1_s, vrag)
 #ifdef MM_W4_DIAG
-      MM_W4_RUN_NN_DIAG(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s)
+      MM_W4_RUN_NN_DIAG(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s, nkm1_s, vrag)
 #endif
     } else {
       const unsigned rdb1 = rdb_hi;
@@ -1623,15 +1629,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
         rdb_hi = (unsigned)(((wn * 4 + ks_swz(k)) & 7) * 32);
       }
       const unsigned voffa0 = toa[0], voffa1 = toa[1], voffb0 = tob[0];
+      const unsigned vrag = rag_mask(lane_in);
       const unsigned a0 = ha.w0, a1 = ha.w1, a2 = ha.w2, b0 = hb.w0, b1 = hb.w1, b2 = hb.w2;
       const unsigned z = w4_sgpr(0u);
       const unsigned rda0 = rda_lo, rda1 = rda_hi, rdb0 = rdb_lo, rdb1 = rdb_hi;      // stage 0
       const unsigned dst = w4_sgpr((unsigned)w * 1024u);
       const unsigned tbh0 = B_KC ? w4_sgpr(32u * ldb2) : w4_sgpr(16u * ldb2), tbh1 = w4_sgpr(64u * ldb2);
       if constexpr (B_KC)
-        asm volatile(MM_W4_ASM_NT_H : : MM_W4_INPUTS_NT_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, tbh1, tbh1, nk_s, dst, wv_s) : MM_W4_CLOBBERS);
+        asm volatile(MM_W4_ASM_NT_H : : MM_W4_INPUTS_NT_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, tbh1, tbh1, nk_s, dst, wv_s, nkm1_s, vrag, vrag) : MM_W4_CLOBBERS);
       else if constexpr (A_KC)
-        asm volatile(MM_W4_ASM_NN_H : : MM_W4_INPUTS_NN_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s) : MM_W4_CLOBBERS);
+        asm volatile(MM_W4_ASM_NN_H : : MM_W4_INPUTS_NN_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s, nkm1_s, vrag) : MM_W4_CLOBBERS);
       else
         asm volatile(MM_W4_ASM_TN_H : : MM_W4_INPUTS_TN_H(voffa0, voffa1, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s) : MM_W4_CLOBBERS);
       int lane = l;
@@ -2511,7 +2518,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       // (a last round at most half full: its tiles are cut into 256 x 128 halves, g.tail -- plain epilogue kinds only)
       const int64_t rem4 = g_opt_persist ? nwg % ncu : 0;
       const bool tail4 = g_opt_tail && !g.swi_I && !g.rope_cols && !(epilogue & MM_EPI_SWIGLU_BWD) && rem4 > 0 && 2 * rem4 <= ncu;
-      if (g_opt_w4 && variant == 2 && ((K & 63) == 0 || layout == MM_GEMM_TN) && K >= 192 && !g.ss && !acts) {
+      if (g_opt_w4 && variant == 2 && K >= 192 && !g.ss && !acts) {
         int64_t nb4 = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
         if (tail4) {
           g.tail = (int)rem4;

@@ -51,10 +51,23 @@ def check():
     cases = [(NT, 8192, 4096, 4096), (NT, 5112, 6144, 4096), (NT, 1000, 1544, 320), (NT, 2049, 4104, 1024), (NT, 8192, 4096, 14336),
              (NN, 8192, 4096, 6144), (NN, 5112, 4096, 4096), (NN, 1111, 1032, 448), (NN, 4096, 14336, 4096), (NN, 300, 520, 192),
              (TN, 4096, 4096, 8192), (TN, 6144, 4096, 8192), (TN, 1000, 1544, 320), (TN, 4096, 14336, 8192), (TN, 777, 2056, 1024),
-             (TN, 4096, 4096, 5112), (TN, 6144, 4096, 5112), (TN, 520, 300, 203), (TN, 2048, 4104, 1001)]
+             (TN, 4096, 4096, 5112), (TN, 6144, 4096, 5112), (TN, 520, 300, 203), (TN, 2048, 4104, 1001),
+             (NT, 1000, 1544, 328), (NT, 2049, 4104, 1000), (NT, 4096, 4096, 4104), (NN, 300, 520, 200), (NN, 1111, 1032, 456), (NN, 5112, 4096, 128258)]
     for lay, M, N, Kd in cases:
-        a = rnd(g, M, Kd) if lay != TN else rnd(g, Kd, pad64(M))[:, :M]
-        b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, pad64(N))[:, :N]
+        if lay != TN and Kd % 64:         # ragged K on a K-contiguous operand: what lies beyond K in a row must not be read (NaN x 0 = NaN)
+            abuf = torch.full((M, pad64(Kd)), float("nan"), device="cuda", dtype=torch.bfloat16)
+            abuf[:, :(Kd + 7) // 8 * 8] = 0          # (operands are read in 16-byte chunks: K % 8 != 0 needs zeros up to the chunk's end,
+            abuf[:, :Kd] = rnd(g, M, Kd)             # as mm_ce_bwd leaves them for the lm_head gradient)
+            a = abuf[:, :Kd]
+        else:
+            a = rnd(g, M, Kd) if lay != TN else rnd(g, Kd, pad64(M))[:, :M]
+        if lay == NT and Kd % 64:
+            bbuf = torch.full((N, pad64(Kd)), float("nan"), device="cuda", dtype=torch.bfloat16)
+            bbuf[:, :(Kd + 7) // 8 * 8] = 0
+            bbuf[:, :Kd] = rnd(g, N, Kd)
+            b = bbuf[:, :Kd]
+        else:
+            b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, pad64(N))[:, :N]
         res = rnd(g, M, N)
         for kind in ("plain", "residual", "accumulate"):
             def run():
