@@ -250,6 +250,9 @@ class _TowerGraphs:
 
     def __init__(self, experts, pixels, tower):
         from ... import functional as F_
+        import gc
+        torch.cuda.synchronize()            # garbage (older graphs, their pools) goes now, at a quiet point, not in the middle of the
+        gc.collect()                        # warm-up / capture / first replay below
         self.experts = experts
         self.params = [p for ex in experts for p in ex.parameters() if p.requires_grad]
         dev = pixels.device

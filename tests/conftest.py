@@ -16,3 +16,28 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu_memory_between_modules(request):
+    """Between test modules on the GPU: collect garbage (and hand cached blocks back).  Round 4: with the models, trainers and captured
+    hipGraphs of seven earlier modules still uncollected, the first replay of a freshly captured MoE tower graph segfaulted inside
+    the HIP runtime -- only in the full-suite order, every module passes alone and in pairs; collecting at module boundaries (outside
+    any capture, after a device synchronisation) removes it.  MM_TEST_MEMLOG=<file>: log what is allocated / reserved at every
+    boundary; MM_TEST_KEEP_CACHE=1: keep the caching allocator's blocks."""
+    yield
+    try:
+        import torch
+    except Exception:
+        return
+    if not torch.cuda.is_available():
+        return
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    log = os.environ.get("MM_TEST_MEMLOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(f"{request.module.__name__}: allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB\n")
+    if os.environ.get("MM_TEST_KEEP_CACHE") != "1":
+        torch.cuda.empty_cache()
