@@ -52,7 +52,8 @@ const char* mm_error_string(int code);
  * issue the LDS-DMA), "attn_fwd_waves" 8|4, "attn_dkv_pair" 0|1; round 4: "gemm_w4" 0 | 1 | n (256x256 tiles on the 4-wave
  * hand-scheduled kernel gemm_bf16_w4_kernel: 0 = the 8-wave kernel, 1 = the shipped schedule, n = another schedule of
  * csrc/gen_gemm_w4.py), "gemm_w4_rowmajor" 0|1 (its row-major, LDS-transposed epilogues), "gemm_w4_stream" 0|1 (wait-free plain
- * epilogue in the accumulator layout), "gemm_w4_group_m", "gemm_w4_stagger" (experiments).  Unknown names return MM_ERR_ARG.   */
+ * epilogue in the accumulator layout), "gemm_w4_shuffle" (0; 1 = the plain epilogue by register lane exchange instead of the LDS round trip: bit-identical, measured equal),
+ * "gemm_w4_group_m", "gemm_w4_stagger" / "gemm_w4_stagger_slots" (experiments).  Unknown names return MM_ERR_ARG.   */
 int mm_set_option(const char* name, int value);
 /* current value of a "gemm_*" switch (so that a caller that flips one temporarily can restore what it found) */
 int mm_get_option(const char* name, int* value);

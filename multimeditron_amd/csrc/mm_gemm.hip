@@ -58,7 +58,10 @@ struct GemmArgs {
   float* ss;
   int group_m;                  // 4-wave kernel: GROUP_M of the tile order (8)
   int stream_epi;               // 4-wave kernel: the plain epilogue without waits between its stores (gemm_epilogue_plain_stream)
-  int stagger;                  // 4-wave kernel: start delay in cycles per (blockIdx.x & 7) -- spreads the workgroups' epilogue bursts (experiment)
+  int shuffle;                  // 4-wave kernel: plain stores by register lane exchange instead of the LDS round trip (w4_shuffle_half)
+  int diag_epi;                 // MM_W4_DIAG builds only: bits that drop parts of the row-major epilogue (timing-only; tools/w4_stamps.py)
+  int stagger, stagger_slots;   // 4-wave kernel: start delay in cycles per slot ((blockIdx.x >> 3) % slots: workgroups that share an XCD, whose L2 write
+                                // path is what a round's epilogue burst queues at) -- spreads the bursts inside every XCD
   int rowmajor;                 // 4-wave kernel: the plain epilogue in its row-major form (16-byte accesses; set by the host when alignment allows)
 };
 constexpr int MM_EPI_SWIGLU_BWD = 1 << 20;   // internal epilogue flag (mm_gemm_swiglu_bwd), not part of the ABI enum
@@ -1185,6 +1188,9 @@ __device__ __forceinline__ void w4_rm_block(const GemmArgs& g, char* xp, __amdgp
   {   // the block leaves the accumulator registers for LDS without passing through VGPRs (w4_store_acc_blk)
     const unsigned xb = (unsigned)(uintptr_t)LDS_PTR(char, xp) + (unsigned)(wr * 256);
     __builtin_amdgcn_wave_barrier();
+#ifdef MM_W4_DIAG
+    if (!(g.diag_epi & 4))
+#endif
     w4_store_acc_blk<IP, C>(xb + (unsigned)(((0 + wq) ^ wr) * 16), xb + (unsigned)(((4 + wq) ^ wr) * 16), xb + (unsigned)(((8 + wq) ^ wr) * 16),
                             xb + (unsigned)(((12 + wq) ^ wr) * 16));
     __builtin_amdgcn_wave_barrier();
@@ -1201,8 +1207,14 @@ __device__ __forceinline__ void w4_rm_block(const GemmArgs& g, char* xp, __amdgp
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + r8;
-    const f32x4 lo = *(const f32x4*)(xp + row * 256 + (((2 * c8) ^ (row & 15)) * 16));
-    const f32x4 hi = *(const f32x4*)(xp + row * 256 + (((2 * c8 + 1) ^ (row & 15)) * 16));
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#ifdef MM_W4_DIAG
+    if (!(g.diag_epi & 2))
+#endif
+    {
+      lo = *(const f32x4*)(xp + row * 256 + (((2 * c8) ^ (row & 15)) * 16));
+      hi = *(const f32x4*)(xp + row * 256 + (((2 * c8 + 1) ^ (row & 15)) * 16));
+    }
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if (has_bias) {
 #pragma unroll
@@ -1221,6 +1233,9 @@ __device__ __forceinline__ void w4_rm_block(const GemmArgs& g, char* xp, __amdgp
     bf16x8 o;
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+#ifdef MM_W4_DIAG
+    if (g.diag_epi & 1) { asm volatile("" ::"v"(o)); continue; }
+#endif
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, off[it], 0, 0);
   }
   __builtin_amdgcn_wave_barrier();
@@ -1396,6 +1411,66 @@ __device__ __forceinline__ void w4_epilogue_rowmajor(const GemmArgs& g, char* xp
   w4_rm_half<1, MODE>(g, xp, rc, rr, nw, has_bias, l);
 }
 
+// ---- plain stores without the LDS round trip (MODE 0, no bias) -----------------------------------------------------------------
+// Measured (tools/probes/gen_epi_probe.py, tools/w4_stamps.py epi=...): a wave alone on its SIMD issues one vector instruction per
+// 4.3 cycles; 64 `ds_write_b128` of accumulator registers cost the four waves 3 400 cycles of the LDS port, the 64 reads 1 000; a
+// wave-wide 16-byte store costs the CU's store path 16 cycles when it covers 8 rows x one full 128-byte line, and 64 (whatever the
+// other CUs do) when it covers 16 rows x 64 bytes.  So: full lines, and no LDS.  A lane owns columns 4q .. 4q+3 (q = l >> 4) of row
+// r = l & 15 in each 16 x 16 tile; the accumulators are rounded first and the lanes exchange packed bf16 pairs in registers:
+//   level 1, tiles (X, Y) side by side: `v_permlane16_swap` (odd 16-lane rows of X <-> even rows of Y) leaves lane rows q = 0, 2
+//            with columns 0-7, 8-15 of X and q = 1, 3 with those of Y: 16 bytes = 8 consecutive columns per lane (P = 32 columns);
+//   level 2, blocks (P0, P1) side by side: lanes r >= 8 of P0 <-> lanes r < 8 of P1 inside every 16-lane row (two DPP `row_ror:8`
+//            moves with bank masks): P0' = rows 0-7 x all 128 bytes, P1' = rows 8-15 x all 128 bytes.
+// Per row block and 64 columns: 16 accumulator reads, 8 conversions, 4 swaps, ~12 DPP moves, 2 stores -- ~700 instructions per wave
+// and tile, no LDS traffic, no waits.  The value stored is bf16(acc) either way: bit-identical.
+template <int C>
+__device__ __forceinline__ void w4_shuffle_half(const GemmArgs& g, __amdgpu_buffer_rsrc_t rc, int nw, int l) {
+  f32x4 acc[8][4];
+  if constexpr (C == 0) w4_read_acc_c0(acc);
+  else w4_read_acc_c1(acc);
+  const int r = l & 15, q = l >> 4;
+  const int chunk = (r >= 8 ? 4 : 0) + (((q & 1) << 1) | (q >> 1));      // the lane's 16-byte chunk of the 128-byte line
+  const int n = nw + C * 64 + chunk * 8;
+  const unsigned colb = n < g.N ? (unsigned)n * 2u : EPI_OOB;
+  const unsigned ld2 = (unsigned)g.ldc * 2u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u32x4 P[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f32x4 x = acc[i][2 * p], y = acc[i][2 * p + 1];
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = (bf16)x[e]; o[4 + e] = (bf16)y[e]; }
+      const u32x4 pk = __builtin_bit_cast(u32x4, o);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0], pk[2], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(pk[1], pk[3], false, false);
+      P[p] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+    }
+    u32x4 lo, hi;                                   // lo: rows 0-7 of the row block, hi: rows 8-15, 128 bytes per row each
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = (unsigned)__builtin_amdgcn_update_dpp((int)P[0][e], (int)P[1][e], 0x128, 0xF, 0xC, false);      // row_ror:8 into lanes r >= 8
+      hi[e] = (unsigned)__builtin_amdgcn_update_dpp((int)P[1][e], (int)P[0][e], 0x128, 0xF, 0x3, false);      // row_ror:8 into lanes r < 8
+    }
+    const unsigned off = colb == EPI_OOB ? EPI_OOB : (unsigned)(i * 16 + (r & 7)) * ld2 + colb;
+    const unsigned off8 = colb == EPI_OOB ? EPI_OOB : off + 8u * ld2;
+#ifdef MM_W4_DIAG
+    if (g.diag_epi & 1) { asm volatile("" ::"v"(lo), "v"(hi)); continue; }
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(lo, rc, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rc, off8, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void w4_epilogue_shuffle(const GemmArgs& g, int mw, int nw, int l) {
+  mw = __builtin_amdgcn_readfirstlane(mw);
+  nw = __builtin_amdgcn_readfirstlane(nw);
+  auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)(g.M - mw) * g.ldc * 2);
+  w4_shuffle_half<0>(g, rc, nw, l);
+  w4_shuffle_half<1>(g, rc, nw, l);
+}
+
 __device__ __forceinline__ unsigned w4_sgpr(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
 
 template <bool A_KC, bool B_KC, int EK, int SCHED>
@@ -1418,7 +1493,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
   const int swi = (EK == 3) ? g.swi_I : (EK == 4 ? -1 : 0);       // B-row gather of the fused gate|up / RoPE tiles (gather_row)
   const int nstep = swi > 0 ? 128 : 256;
   if (g.stagger > 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), wait = (unsigned long long)g.stagger * (blockIdx.x & 7);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), wait = (unsigned long long)g.stagger * ((blockIdx.x >> 3) % (unsigned)g.stagger_slots);
     while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
   }
   int pm, pn;
@@ -1558,7 +1633,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
       w4_epilogue_swiglu_bwd_rowmajor(g, smem + 131072 + w * 8192, mw, n0 + wn * 128, lane);
     } else if (EK == 0 && g.rowmajor && emode != 3) {
       char* xp = smem + 131072 + w * 8192;
-      if (emode == 0) w4_epilogue_rowmajor<0>(g, xp, mw, n0 + wn * 128, lane);
+#ifdef MM_W4_DIAG
+      if (g.diag_epi & 8) {} else
+#endif
+      if (emode == 0 && g.shuffle && !(g.epi & MM_EPI_BIAS)) w4_epilogue_shuffle(g, mw, n0 + wn * 128, lane);
+      else if (emode == 0) w4_epilogue_rowmajor<0>(g, xp, mw, n0 + wn * 128, lane);
       else if (emode == 1) w4_epilogue_rowmajor<1>(g, xp, mw, n0 + wn * 128, lane);
       else w4_epilogue_rowmajor<2>(g, xp, mw, n0 + wn * 128, lane);
     } else {
@@ -1652,7 +1731,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
         const int rows = g.M - mwu;
         auto rc = make_rsrc((const bf16*)g.C + (int64_t)mwu * g.ldc, (int64_t)rows * g.ldc * 2);
         auto rr = emode == 1 ? make_rsrc((const bf16*)g.residual + (int64_t)mwu * g.ldr, (int64_t)rows * g.ldr * 2) : rc;
-        if (emode == 0) w4_rm_half<0, 0>(g, xp, rc, rr, nwu, has_bias, lane);
+        if (emode == 0 && g.shuffle && !has_bias) w4_shuffle_half<0>(g, rc, nwu, lane);
+        else if (emode == 0) w4_rm_half<0, 0>(g, xp, rc, rr, nwu, has_bias, lane);
         else if (emode == 1) w4_rm_half<0, 1>(g, xp, rc, rr, nwu, has_bias, lane);
         else w4_rm_half<0, 2>(g, xp, rc, rr, nwu, has_bias, lane);
       } else {
@@ -2168,6 +2248,9 @@ static int g_opt_w4_big = 1;        // schedule of the 4-wave kernel on wide-N /
                                     // SwiGLU GEMMs alone, 348.6 vs 352.2 ms at step level, tools/step_ab.py: off)
 static int g_opt_w4_group_m = 8;    // experiment: GROUP_M of the 4-wave kernel's tile order
 static int g_opt_w4_stream = 1;     // 4-wave kernel: wait-free plain epilogue (0 = gemm_epilogue_plain_pipe, A/B)
+static int g_opt_w4_shuffle = 0;    // GemmArgs::shuffle (measured equal to the LDS form within +-0.5 %: DESIGN.md section 4, the round-4 list, item 6)
+static int g_opt_w4_diag_epi = 0;   // MM_W4_DIAG builds: GemmArgs::diag_epi
+static int g_opt_w4_stagger_slots = 4;
 static int g_opt_w4_stagger = 0;    // experiment: see GemmArgs::stagger
 static int g_opt_w4_rowmajor = 1;   // 4-wave kernel: row-major (LDS-transposed, 16-byte) plain epilogue; 0 = the accumulator-layout epilogue (A/B)
 static int g_opt_w4 = [] { const char* e = getenv("MM_GEMM_W4"); return e ? atoi(e) : 1; }();            // (MM_GEMM_W4=0: A/B at step level) NT / NN 256x256 tiles on the 4-wave hand-scheduled kernel (gemm_bf16_w4_kernel); 0 = the 8-wave kernel (A/B)
@@ -2206,6 +2289,9 @@ extern "C" int mm_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_w4_big")) { if (value != 1 && value != 4) return MM_ERR_ARG; g_opt_w4_big = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4_group_m")) { if (value < 1) return MM_ERR_ARG; g_opt_w4_group_m = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4_stream")) { g_opt_w4_stream = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_shuffle")) { g_opt_w4_shuffle = value != 0; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_diag_epi")) { g_opt_w4_diag_epi = value; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_stagger_slots")) { if (value < 1 || value > 32) return MM_ERR_ARG; g_opt_w4_stagger_slots = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4_stagger")) { if (value < 0) return MM_ERR_ARG; g_opt_w4_stagger = value; return MM_OK; }
   if (!strcmp(name, "gemm_w4")) { if (value < 0) return MM_ERR_ARG; g_opt_w4 = value; return MM_OK; }      // 0 off, 1 the shipped schedule, n > 1: gen_gemm_w4.py SCHEDS
   if (!strcmp(name, "gemm_kernel")) { if (value < 0 || value > 6) return MM_ERR_ARG; g_opt_kernel = value; return MM_OK; }
@@ -2225,6 +2311,7 @@ extern "C" int mm_get_option(const char* name, int* value) {
   if (!strcmp(name, "gemm_issue_waves")) { *value = g_opt_issue_waves; return MM_OK; }
   if (!strcmp(name, "gemm_w4")) { *value = g_opt_w4; return MM_OK; }
   if (!strcmp(name, "gemm_w4_rowmajor")) { *value = g_opt_w4_rowmajor; return MM_OK; }
+  if (!strcmp(name, "gemm_w4_shuffle")) { *value = g_opt_w4_shuffle; return MM_OK; }
   if (!strcmp(name, "gemm_kernel")) { *value = g_opt_kernel; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -2527,6 +2614,9 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
         dim3 grid4((unsigned)nb4), block4(256);
         const size_t lds = 160 * 1024;                  // the ring (128 KB) + 8 KB per wave for the row-major epilogue's transposition
         g.stagger = g_opt_w4_stagger;
+        g.stagger_slots = g_opt_w4_stagger_slots;
+        g.diag_epi = g_opt_w4_diag_epi;
+        g.shuffle = g_opt_w4_shuffle;
         g.group_m = g_opt_w4_group_m;
         g.stream_epi = g_opt_w4_stream;
         g.rowmajor = g_opt_w4_rowmajor && (N & 7) == 0 && (ldc & 7) == 0 && mm_aligned16(C) &&

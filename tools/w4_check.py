@@ -260,9 +260,12 @@ if __name__ == "__main__":
     stg = [a for a in sys.argv if a.startswith("--stagger=")]
     if stg:                                 # start delay per XCD slot (cycles): 0 = off
         vals = [int(x) for x in stg[0][10:].split(",")]
+        sl = [a for a in sys.argv if a.startswith("--slots=")]
+        if sl:
+            set_opt("gemm_w4_stagger_slots", int(sl[0][8:]))
         T = 8192
         g = torch.Generator(device="cuda").manual_seed(0)
-        for lay, M, N, Kd in ((NT, T, 4096, 4096), (NT, T, 28672, 4096), (NT, T, 4096, 14336), (NN, T, 14336, 4096), (TN, 28672, 4096, T)):
+        for lay, M, N, Kd in ((NT, T, 4096, 4096), (NT, T, 4096, 1024), (NT, T, 6144, 4096), (NT, T, 28672, 4096), (NT, T, 4096, 14336), (NN, T, 14336, 4096), (TN, 28672, 4096, T), (TN, 4096, 4096, T)):
             a = rnd(g, M, Kd) if lay != TN else rnd(g, Kd, M)
             b = rnd(g, N, Kd) if lay == NT else rnd(g, Kd, N)
             c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
@@ -294,9 +297,10 @@ if __name__ == "__main__":
             c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             t, outs = {}, {}
             for rep in range(5):
-                for mode in (0, 1, 2):          # 0 round-3 pipelined epilogue, 1 wait-free accumulator layout, 2 wait-free row-major
-                    set_opt("gemm_w4_stream", 1 if mode else 0)
-                    set_opt("gemm_w4_rowmajor", 1 if mode == 2 else 0)
+                for mode in (0, 1, 2, 3):       # 0 round-3 pipelined epilogue, 1 wait-free accumulator layout, 2 wait-free row-major through LDS,
+                    set_opt("gemm_w4_stream", 1 if mode else 0)          # 3 = 2 with the plain case by register lane exchange (the default)
+                    set_opt("gemm_w4_rowmajor", 1 if mode >= 2 else 0)
+                    set_opt("gemm_w4_shuffle", 1 if mode == 3 else 0)
                     kw = dict(residual=res if kind == "residual" else None, accumulate=kind == "accumulate")
                     c.copy_(res)
                     K.gemm(lay, a, b, M, N, Kd, out=c, **kw)
@@ -310,8 +314,8 @@ if __name__ == "__main__":
                     t.setdefault(mode, []).append(e0.elapsed_time(e1) / 3)
             fl = 2.0 * M * N * Kd
             med = {m: sorted(v)[len(v) // 2] for m, v in t.items()}
-            print(f"{LN[lay]} M={M:6d} N={N:6d} K={Kd:6d} {kind:10s} pipe {fl / med[0] / 1e9:6.0f}  stream {fl / med[1] / 1e9:6.0f}  row-major {fl / med[2] / 1e9:6.0f} TF/s   "
-                  f"{'bit-identical' if torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) else 'DIFFERENT'}", flush=True)
+            print(f"{LN[lay]} M={M:6d} N={N:6d} K={Kd:6d} {kind:10s} pipe {fl / med[0] / 1e9:6.0f}  stream {fl / med[1] / 1e9:6.0f}  row-major {fl / med[2] / 1e9:6.0f}  shuffle {fl / med[3] / 1e9:6.0f} TF/s   "
+                  f"{'bit-identical' if torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]) else 'DIFFERENT'}", flush=True)
         set_opt("gemm_w4_rowmajor", 0)
         set_opt("gemm_w4_stream", 1)
         sys.exit(0)

@@ -8,14 +8,25 @@ from multimeditron_amd import kernels as K
 from multimeditron_amd._lib import lib
 
 L = lib()
+EPI = [0]                                # epi=0,1,2,4,7,8: timing-only epilogue variants (GemmArgs::diag_epi: 1 no global stores, 2 no LDS reads,
+SHAPES = ((8192, 4096, 4096), (8192, 4096, 14336), (8192, 28672, 4096))        # 4 no LDS writes, 8 no epilogue at all)
 for a in sys.argv[1:]:                   # e.g. gemm_w4_rowmajor=0 gemm_w4_stream=0: the round-3 pipelined epilogue
     k, v = a.split("=")
+    if k == "shape":                     # shape=M,N,K[;M,N,K...]
+        SHAPES = tuple(tuple(int(x) for x in t.split(",")) for t in v.split(";"))
+        continue
+    if k == "epi":
+        EPI = [int(x) for x in v.split(",")]
+        continue
     assert L.mm_set_option(k.encode(), int(v)) == 0, a
     print("option", a, flush=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *s: (torch.rand(*s, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
 buf = (ctypes.c_uint * (256 * 4 * 7))()
-for M, N, Kd in ((8192, 4096, 4096), (8192, 4096, 14336), (8192, 28672, 4096)):
+for M, N, Kd, epi in [(m, n, k, e) for (m, n, k) in SHAPES for e in EPI]:
+    assert L.mm_set_option(b"gemm_w4_diag_epi", epi) == 0
+    if len(EPI) > 1:
+        print("diag_epi", epi, end=": ")
     a, b = r(M, Kd), r(N, Kd)
     c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     assert L.mm_set_option(b"gemm_w4", 121) == 0
