@@ -2250,6 +2250,7 @@ static int g_opt_w4_group_m = 8;    // experiment: GROUP_M of the 4-wave kernel'
 static int g_opt_w4_stream = 1;     // 4-wave kernel: wait-free plain epilogue (0 = gemm_epilogue_plain_pipe, A/B)
 static int g_opt_w4_shuffle = 0;    // GemmArgs::shuffle (measured equal to the LDS form within +-0.5 %: DESIGN.md section 4, the round-4 list, item 6)
 static int g_opt_w4_diag_epi = 0;   // MM_W4_DIAG builds: GemmArgs::diag_epi
+static int g_last_kernel = -1;      // which kernel the last bf16 mm_gemm* call launched: 10 = the 4-wave 256x256 kernel, 0..5 = v1 / the 8-wave DMA tiles, 20 = skinny
 static int g_opt_w4_stagger_slots = 4;
 static int g_opt_w4_stagger = 0;    // experiment: see GemmArgs::stagger
 static int g_opt_w4_rowmajor = 1;   // 4-wave kernel: row-major (LDS-transposed, 16-byte) plain epilogue; 0 = the accumulator-layout epilogue (A/B)
@@ -2312,6 +2313,7 @@ extern "C" int mm_get_option(const char* name, int* value) {
   if (!strcmp(name, "gemm_w4")) { *value = g_opt_w4; return MM_OK; }
   if (!strcmp(name, "gemm_w4_rowmajor")) { *value = g_opt_w4_rowmajor; return MM_OK; }
   if (!strcmp(name, "gemm_w4_shuffle")) { *value = g_opt_w4_shuffle; return MM_OK; }
+  if (!strcmp(name, "gemm_last_kernel")) { *value = g_last_kernel; return MM_OK; }       // (bench.py: which launches the roofline's kernel took)
   if (!strcmp(name, "gemm_kernel")) { *value = g_opt_kernel; return MM_OK; }
   return MM_ERR_ARG;
 }
@@ -2544,6 +2546,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
   const void *A = g.A, *B = g.B;
   void* C = g.C;
   if (dtype == MM_BF16) {
+    g_last_kernel = 0;
     if ((lda & 7) || (ldb & 7) || (ldc & 3) || ((epilogue & MM_EPI_RESIDUAL) && (ldr & 3))) return MM_ERR_ALIGN;
     if (!mm_aligned16(A) || !mm_aligned16(B) || (((uintptr_t)C) & 7)) return MM_ERR_ALIGN;
     // kernel choice: the LDS-DMA 256x128 kernel when its grid fills the chip, else the 128x128 register-staged one.
@@ -2563,6 +2566,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
         q.ldr = ldr; q.epi = epilogue;
         return gemv_stream_launch<0>(q, (unsigned)((N + 15) / 16), s);
       }
+      g_last_kernel = 20;
       dim3 grid((unsigned)((N + 15) / 16)), block(512);
       hipLaunchKernelGGL(gemm_skinny_kernel, grid, block, 0, s, g);
       MM_CHECK_LAUNCH();
@@ -2605,7 +2609,9 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
       // (a last round at most half full: its tiles are cut into 256 x 128 halves, g.tail -- plain epilogue kinds only)
       const int64_t rem4 = g_opt_persist ? nwg % ncu : 0;
       const bool tail4 = g_opt_tail && !g.swi_I && !g.rope_cols && !(epilogue & MM_EPI_SWIGLU_BWD) && rem4 > 0 && 2 * rem4 <= ncu;
+      g_last_kernel = variant;
       if (g_opt_w4 && variant == 2 && K >= 192 && !g.ss && !acts) {
+        g_last_kernel = 10;
         int64_t nb4 = g_opt_persist ? (nwg < (int64_t)ncu ? nwg : (int64_t)ncu) : nwg;
         if (tail4) {
           g.tail = (int)rem4;

@@ -38,20 +38,31 @@ for ns_m, k, util, clk, rd, wr, n in rows[:14]:
 # roofline.traffic.  FETCH_SIZE (KiB, x2 on gfx950) and WRITE_SIZE (KiB) come from their own passes, so each is divided
 # by its own launch count.
 import json
-fb = fl = wb = wl = 0.0
-for k, v in agg.items():
-    if "gemm_bf16_dma_kernel" not in k and "gemm_bf16_w4_kernel" not in k:
-        continue
-    fb += 2.0 * v.get("FETCH_SIZE", 0.0) * 1024.0
-    fl += calls[(k, "FETCH_SIZE")]
-    wb += v.get("WRITE_SIZE", 0.0) * 1024.0
-    wl += calls[(k, "WRITE_SIZE")]
-if fl and wl and len(sys.argv) > 2:
+
+
+def family(match):
+    fb = fl = wb = wl = 0.0
+    for k, v in agg.items():
+        if not match(k):
+            continue
+        fb += 2.0 * v.get("FETCH_SIZE", 0.0) * 1024.0
+        fl += calls[(k, "FETCH_SIZE")]
+        wb += v.get("WRITE_SIZE", 0.0) * 1024.0
+        wl += calls[(k, "WRITE_SIZE")]
+    if not (fl and wl):
+        return None
+    return {"read_bytes_per_launch": fb / fl, "write_bytes_per_launch": wb / wl, "bytes_per_launch": fb / fl + wb / wl, "launches_counted": int(fl)}
+
+
+w4 = family(lambda k: "gemm_bf16_w4_kernel" in k)                                       # the dominant kernel: bench.py's roofline.traffic
+allg = family(lambda k: "gemm_bf16_dma_kernel" in k or "gemm_bf16_w4_kernel" in k)       # every bf16 GEMM launch: roofline.all_gemm_launches.traffic
+if w4 and allg and len(sys.argv) > 2:
     import os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from bench import kernel_source_sha
-    json.dump({"kernel_source_sha": kernel_source_sha(), "kernel": "gemm_bf16_w4_kernel + gemm_bf16_dma_kernel (all instantiations)", "read_bytes_per_launch": fb / fl, "write_bytes_per_launch": wb / wl,
-               "bytes_per_launch": fb / fl + wb / wl, "launches_counted": int(fl),
-               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 1 "
-                         "--no-cpu-baseline --no-roofline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 correction); KiB -> bytes"},
-              open(sys.argv[2], "w"), indent=1)
+    d = {"kernel_source_sha": kernel_source_sha(), "kernel": "gemm_bf16_w4_kernel (all instantiations)"}
+    d.update(w4)
+    d["all_gemm_launches"] = dict(allg, kernel="gemm_bf16_w4_kernel + gemm_bf16_dma_kernel (all instantiations)")
+    d["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 1 "
+                   "--no-cpu-baseline --no-roofline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 correction); KiB -> bytes")
+    json.dump(d, open(sys.argv[2], "w"), indent=1)
