@@ -195,7 +195,7 @@ extern "C" int mm_gradnorm_finish(const float* partial, int nblk, float max_norm
   return MM_OK;
 }
 
-int g_adamw_blocks = 0;       // mm_set_option "adamw_blocks": grid cap of the update kernel (0 = MM_ADAMW_BLOCKS or 2048)
+int g_adamw_blocks = 0;       // mm_set_option "adamw_blocks": grid cap of the update kernel (0 = MM_ADAMW_BLOCKS or 262144)
 
 extern "C" int mm_adamw_step(int dtype, void* p, const void* g, float* master, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int step, const float* clip, void* stream) {
@@ -204,9 +204,12 @@ extern "C" int mm_adamw_step(int dtype, void* p, const void* g, float* master, f
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   if (!mm_aligned16(p) || !mm_aligned16(g) || !mm_aligned16(master) || !mm_aligned16(m) || !mm_aligned16(v)) return MM_ERR_ALIGN;
   const int64_t nv4 = (n / 4 + 255) / 256;
-  // grid cap: the update runs on a side stream under the next step's forward; MM_ADAMW_BLOCKS throttles how much of the
-  // chip (and of HBM) it takes while the forward's GEMMs run
-  static const int64_t env_cap = [] { const char* e = getenv("MM_ADAMW_BLOCKS"); const long c = e ? atol(e) : 0; return (int64_t)(c > 0 ? c : 2048); }();
+  // grid cap: the update runs on a side stream under the next step's forward; MM_ADAMW_BLOCKS / "adamw_blocks" throttle how much of
+  // the chip (and of HBM) it takes while the forward runs.  Round 4: 262 144 (one 4-element vector per thread for every tensor of the 8B
+  // model, no grid-stride loop) instead of 2 048: stand-alone 5.1-5.9 -> 6.0-6.4 TB/s (tools/adamw_bench.py), the 8B step 347.6 -> 344.9 ms
+  // median over six interleaved rounds (tools/step_ab.py "opt:adamw_blocks=0" "opt:adamw_blocks=262144").  (8 parameters per thread with
+  // 16-byte p / g / remainder accesses: 3.8 instead of 6.2 TB/s -- m and v then go by 32-byte lane strides; removed.)
+  static const int64_t env_cap = [] { const char* e = getenv("MM_ADAMW_BLOCKS"); const long c = e ? atol(e) : 0; return (int64_t)(c > 0 ? c : 262144); }();
   const int64_t cap = g_adamw_blocks > 0 ? g_adamw_blocks : env_cap;
   const unsigned nb = (unsigned)(nv4 < 1 ? 1 : (nv4 < cap ? nv4 : cap));
   static const bool nt = [] { const char* e = getenv("MM_ADAMW_NT"); return !e || e[0] != '0'; }();
@@ -228,7 +231,7 @@ extern "C" int mm_adamw_step_split(void* p_bf16, const void* g_bf16, void* lo_i1
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   if ((((uintptr_t)p_bf16) & 7) || (((uintptr_t)g_bf16) & 7) || (((uintptr_t)lo_i16) & 7) || !mm_aligned16(m) || !mm_aligned16(v)) return MM_ERR_ALIGN;
   const int64_t nv4 = (n / 4 + 255) / 256;
-  static const int64_t env_cap = [] { const char* e = getenv("MM_ADAMW_BLOCKS"); const long c = e ? atol(e) : 0; return (int64_t)(c > 0 ? c : 2048); }();
+  static const int64_t env_cap = [] { const char* e = getenv("MM_ADAMW_BLOCKS"); const long c = e ? atol(e) : 0; return (int64_t)(c > 0 ? c : 262144); }();
   const int64_t cap = g_adamw_blocks > 0 ? g_adamw_blocks : env_cap;
   const unsigned nb = (unsigned)(nv4 < 1 ? 1 : (nv4 < cap ? nv4 : cap));
   static const bool nt = [] { const char* e = getenv("MM_ADAMW_NT"); return !e || e[0] != '0'; }();

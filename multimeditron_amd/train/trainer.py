@@ -640,7 +640,8 @@ class MultimodalTrainer:
         decoder's GEMMs the update costs MORE: the 256x256 GEMM's LDS-DMA stream shares HBM with 5 TB/s of optimizer traffic and
         loses about 0.8 ms per ms of update, wherever the update is placed; the ViT forward, being launch-latency-bound, is the
         cheapest thing to run it beside.  (A smaller update grid, `mm_set_option("adamw_blocks", 512)`: 388.6-393.8 vs 394.2,
-        inside the noise.)  The update therefore costs the step about 35 of its 44 ms on this chip; fewer bytes per parameter
+        inside the noise; round 4: a LARGER grid -- 262 144, one vector per thread, now the library's default --
+        is 8-18 % faster stand-alone and 2.7 ms per step: csrc/mm_optim.hip.)  The update therefore costs the step about 35 of its 44 ms on this chip; fewer bytes per parameter
         (28 now) is what would lower it."""
         upd = self._deferred
         if upd is None:
