@@ -13,7 +13,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T* g, int64_t n, float
   constexpr int VN = Vec16<T>::N;
   float s = 0.f;
   const int64_t nv = n / VN;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+  const int64_t st = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * st < nv; i += 4 * st) {          // four independent 16-byte loads in flight per thread (one per iteration left the sweep at 5.1 TB/s)
+    Vec16<T> v0 = *(const Vec16<T>*)(g + i * VN), v1 = *(const Vec16<T>*)(g + (i + st) * VN), v2 = *(const Vec16<T>*)(g + (i + 2 * st) * VN),
+             v3 = *(const Vec16<T>*)(g + (i + 3 * st) * VN);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) s += v0.get(k) * v0.get(k);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) s += v1.get(k) * v1.get(k);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) s += v2.get(k) * v2.get(k);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) s += v3.get(k) * v3.get(k);
+  }
+  for (; i < nv; i += st) {
     Vec16<T> v = *(const Vec16<T>*)(g + i * VN);
 #pragma unroll
     for (int k = 0; k < VN; ++k) s += v.get(k) * v.get(k);

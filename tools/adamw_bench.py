@@ -28,3 +28,16 @@ for blocks in (2048, 16384, 0, 1048576, 2048, 0):
     ms = e0.elapsed_time(e1) / 5
     print(f"adamw_blocks={blocks:7d} (0 = default 262144): {ms:7.3f} ms for {n / 2**20:.0f} Mi parameters = {26.0 * n / ms / 1e9:6.2f} TB/s", flush=True)
 lib().mm_set_option(b"adamw_blocks", 0)
+
+# the gradient-norm sweep (mm_gradnorm_partial: one read of the gradients)
+part = torch.empty(1024, device=dev, dtype=torch.float32)
+for _ in range(2):
+    K.gradnorm_partial(g, part)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    K.gradnorm_partial(g, part)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+print(f"gradnorm_partial, 1024 workgroups: {ms:7.3f} ms for {n / 2**20:.0f} Mi bf16 gradients = {2.0 * n / ms / 1e9:6.2f} TB/s; sum {float(part.sum()):.6e} (torch {float((g.float() ** 2).sum()):.6e})")
