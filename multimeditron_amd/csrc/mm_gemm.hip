@@ -2244,11 +2244,11 @@ static int small_variant(int M, int N, int K) {
 }
 static int g_opt_epi_pipe = 1;      // pipelined, branch-free epilogue of the plain / SwiGLU-backward LDS-DMA kernels
 static int g_opt_issue_waves = 4;   // waves that issue the 256x256 kernel's DMA (4 staggers the two waves of each SIMD)
-static int g_opt_w4_big = 1;        // schedule of the 4-wave kernel on wide-N / long-K NT and NN problems: 1, or 4 (split barriers: +2...+5 % on the fused
+static int g_opt_w4_big = 4;        // 4 = the split-barrier schedule 4 for operands that stream from HBM (N or K >= 14336), 1 = schedule 1 everywhere.  Step A/B, three series on three boxes: 354.2 / 348.6 / 353.9 vs 355.6 / 352.2 / 355.4 ms (medians)
                                     // SwiGLU GEMMs alone, 348.6 vs 352.2 ms at step level, tools/step_ab.py: off)
 static int g_opt_w4_group_m = 8;    // experiment: GROUP_M of the 4-wave kernel's tile order
 static int g_opt_w4_stream = 1;     // 4-wave kernel: wait-free plain epilogue (0 = gemm_epilogue_plain_pipe, A/B)
-static int g_opt_w4_shuffle = 0;    // GemmArgs::shuffle (measured equal to the LDS form within +-0.5 %: DESIGN.md section 4, the round-4 list, item 6)
+static int g_opt_w4_shuffle = 0;    // GemmArgs::shuffle (measured equal to the LDS form within +-0.5 %: DESIGN.md section 4, the round-4 list, item 8)
 static int g_opt_w4_diag_epi = 0;   // MM_W4_DIAG builds: GemmArgs::diag_epi
 static int g_last_kernel = -1;      // which kernel the last bf16 mm_gemm* call launched: 10 = the 4-wave 256x256 kernel, 0..5 = v1 / the 8-wave DMA tiles, 20 = skinny
 static int g_opt_w4_stagger_slots = 4;
