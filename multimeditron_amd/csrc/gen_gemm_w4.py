@@ -39,6 +39,8 @@ FR = {("A", 0): 128, ("B", 0): 160, ("A", 1): 192, ("B", 1): 224}
 V_RD = {"A": 116, "B": 92}
 V_VOFF = {"A": 100, "B": 108}
 V_TMP = 124
+V_PF = {"A": 125, "B": 126}      # per-lane byte offsets of the prefetch loads (inputs pfa / pfb); v127 = where they land (never read)
+V_PFDST = 127
 S_DESC = {"A": 64, "B": 68}
 S_KD, S_LOOP, S_M0, S_DST, S_T0, S_SB = 78, 84, 85, 86, 87, 88
 TILE_OFF = {"A": 0, "B": 32768}
@@ -52,7 +54,7 @@ class Sched:
 
     def __init__(self, sid, ra=(0, 40), tog=(44, 62), rb=(0, 44), dma0=1, dma_stride=2, book0=44, coarse=True,
                  no_dma=False, no_reads=False, no_sync=False, no_vmwait=False, no_barrier=False, oob_dma=False, diag=False,
-                 wave_shift=0, read_shift=0, stamps=False, split=None):
+                 wave_shift=0, read_shift=0, stamps=False, split=None, pf=0):
         self.sid, self.ra, self.tog, self.rb, self.dma0, self.dma_stride, self.book0 = sid, ra, tog, rb, dma0, dma_stride, book0
         self.coarse, self.no_dma, self.no_reads, self.no_sync, self.diag = coarse, no_dma, no_reads, no_sync, diag
         self.no_vmwait, self.no_barrier, self.oob_dma = no_vmwait, no_barrier, oob_dma
@@ -63,6 +65,12 @@ class Sched:
         # stage(s) -> DMA(s+2) starts there, n pieces still in phase A; Y (phase B, behind MFMA ygap): every wave's DMA(s+1) has landed
         # -> the set-0 reads of step s+1 follow.  A piece gets 105-168 MFMAs to land instead of 68-128.
         self.split = split
+        # pf = d > 0: L2 prefetch.  Behind the last DMA piece of K-step s + 2 every wave touches, with one 4-byte load per 128-byte line, the lines
+        # its workgroup's DMA will ask for d K-steps later (K-step s + 2 + d): 64 lines per instruction, one instruction per operand for a
+        # K-contiguous operand (the wave's 64 rows), one for a K-strided one (64 k-rows x the wave's line of the 512-byte row).  vmcnt retires in
+        # order, so the waits become vmcnt(2): a prefetch may stay in flight across ONE barrier and is waited for at the next -- a deadline of
+        # ~1.5 K-steps (3 000+ cycles) for the HBM round trip, after which the DMA itself finds its lines in L2.
+        self.pf = pf
         self.stamps = stamps          # s_memtime around every barrier: cycles spent at it (sum, max) and in the whole loop -> asm outputs
         self.copies = 4 if (wave_shift or read_shift) else 1
 
@@ -75,6 +83,8 @@ SCHEDS = [
     Sched(3, dma0=0, dma_stride=4, coarse=False),   # counted lgkmcnt waits instead of one per K-step
     Sched(4, dma0=2, dma_stride=4, coarse=False, ra=(0, 32), book0=16, split=(44, 20, 5), rb=(21, 53)),
     Sched(5, dma0=2, dma_stride=4, coarse=False, ra=(0, 30), book0=8, split=(36, 28, 7), rb=(29, 57)),
+    Sched(6, dma0=0, dma_stride=4, pf=2),                                                      # schedule 1 + L2 prefetch two K-steps ahead of the DMA
+    Sched(7, dma0=2, dma_stride=4, coarse=False, ra=(0, 32), book0=16, split=(44, 20, 5), rb=(21, 53), pf=2),      # schedule 4 + the same
     # ---- timing-only builds (-DMM_W4_DIAG, tools/build_diag.sh): each drops one ingredient of schedule 1
     Sched(111, dma0=0, dma_stride=4, no_dma=True, diag=True),
     Sched(112, dma0=0, dma_stride=4, no_reads=True, diag=True),
@@ -145,8 +155,8 @@ class Emitter:
         self.out.append("s_waitcnt lgkmcnt(0)")
         self.done_upto = self.lds_issued
 
-    def full_wait(self):
-        self.out.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    def full_wait(self, vm=0):
+        self.out.append(f"s_waitcnt vmcnt({vm}) lgkmcnt(0)")
         self.done_upto = self.lds_issued
 
 
@@ -220,6 +230,11 @@ def gen_variant(v, sc):
             else:                # 128 wide: one lane pattern, 16 k-rows between consecutive pieces
                 for k in range(1, 4):
                     e.raw(f"v_add_u32 v{vo + k}, %[tb0], v{vo + k - 1}")
+    if sc.pf:
+        for X, p in (("A", "a"), ("B", "b")):
+            e.raw(f"v_mov_b32 v{V_PF[X]}, %[pf{p}]")
+            if not v.kc[X]:              # K-strided: d K-steps = d x 64 rows, as an SGPR offset (s80 / s81)
+                e.raw(f"s_mul_i32 s{80 + (X == 'B')}, {stepA if X == 'A' else stepB}, {sc.pf}")
     # LDS read addresses
     for X, p in (("A", "a"), ("B", "b")):
         if v.kc[X]:
@@ -288,6 +303,13 @@ def gen_variant(v, sc):
                 g0, n0 = g0 + 1, 0.0
         assert g0 < (sc.split[0] if sc.split else NG - 1), (g0, NG)
         NP = 8 + v.nj                                # DMA pieces of a wave per K-step
+        NPF = 2 if sc.pf else 0                      # prefetch loads of a wave per K-step (one per operand)
+
+        def pf_load(X):
+            d = S_DESC[X]
+            if v.kc[X]:
+                return ("raw", f"buffer_load_dword v{V_PFDST}, v{V_PF[X]}, s[{d}:{d + 3}], 0 offen offset:{sc.pf * 128}")
+            return ("raw", f"buffer_load_dword v{V_PFDST}, v{V_PF[X]}, s[{d}:{d + 3}], s{80 + (X == 'B')} offen")
 
         def dma_piece(k):
             X, i = ("A", k) if k < 8 else ("B", k - 8)
@@ -327,7 +349,7 @@ def gen_variant(v, sc):
             if sc.no_vmwait:
                 e.lgkm_wait()
             else:
-                e.full_wait()
+                e.full_wait(0 if first else NPF)       # (a tile's first P: what is younger than DMA(1) there is not known -- the epilogue's traffic)
             if not sc.no_barrier:
                 e.raw("s_barrier")
             if sc.stamps:
@@ -357,7 +379,8 @@ def gen_variant(v, sc):
                 m0w, ld = dma_piece(k)
                 aux[g - 1].append(m0w)
                 aux[g].append(ld)
-            aux[ygap].append(("ybar", younger))
+            aux[ygap].append(("ybar", younger + (0 if first else NPF)))
+            last_dma = max(sc.dma0 + sc.dma_stride * (k - na) for k in range(na, NP))
         else:
             for k in range(NP):
                 g = sc.dma0 + sc.dma_stride * k + sc.wave_shift * wv          # the DMA's gap; M0 is written one gap earlier (a wait state)
@@ -369,6 +392,12 @@ def gen_variant(v, sc):
                 if not sc.no_dma:
                     aux[g].append(ld)
         assert sc.split or sc.dma0 + sc.dma_stride * (NP - 1) + sc.wave_shift * 3 <= NG - 1
+        if sc.pf:                                    # behind the step's last DMA piece (program order = what the counted waits assume)
+            if not sc.split:
+                last_dma = sc.dma0 + sc.dma_stride * (NP - 1)
+            assert last_dma + 2 <= NG - 1, last_dma
+            aux[last_dma + 1].append(pf_load("A"))
+            aux[last_dma + 2].append(pf_load("B"))
         aux[NG - 1].append(("raw", f"s_xor_b32 s{S_DST}, s{S_DST}, {STAGE}"))      # the stage the next K-step's DMA refills
         m = 0
         for a in pre:
@@ -439,7 +468,7 @@ def operands(v):
         ops += [(f"{p}{q}", "s") for q in range(3)]
     ops += [("ta", "s")]
     ops += [("tb0", "s")] + ([("tb1", "s"), ("tb2", "s")] if v.kc["B"] else [])
-    ops += [("nk", "s"), ("dst", "s"), ("wv", "s")]
+    ops += [("nk", "s"), ("dst", "s"), ("wv", "s"), ("pfa", "v"), ("pfb", "v")]
     if v.kc["A"] or v.kc["B"]:
         ops += [("nkm1", "s")] + [(f"vrag{X.lower()}", "v") for X in "AB" if v.kc[X]]
     return ops

@@ -1580,19 +1580,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
     dma_offsets<B_KC, 256, 4>(tob, g.ldb, swi, lane_in);
     const unsigned voffa0 = toa[0], voffa1 = toa[1], voffb0 = tob[0], voffb1 = tob[1];
     const unsigned vrag = rag_mask(lane_in);
+    // L2 prefetch (schedules 6, 7; gen_gemm_w4.py `pf`): the lane's line of the wave's share of a K-step.  K-contiguous operand: row
+    // (w + 4 (l >> 3)) * 8 + (l & 7) of the tile (the rows of the wave's DMA pieces), first bytes of the K-step; K-strided: k-row l,
+    // line w of the 512-byte row
+    // One workgroup per shared panel does it: in an XCD's 8 x 4 block of concurrent tiles (block_to_tile) a row panel of A is read by 4
+    // workgroups and a column panel of B by 8, all at the same K-step; every one of them prefetching doubled the L2 request count and
+    // cost 5-10 % (tools/w4_check.py --scheds=1,4,6,7).  The others pass an out-of-range offset (bit 31: adding the instruction offset cannot wrap):
+    // the instruction issues, nothing moves.
+    const int tpm = m0 >> 8, tpn = n0 / nstep;
+    const bool pf_a = (tpn & 3) == (tpm & 3), pf_b = (tpm & 7) == (tpn & 7);
+    const unsigned pfa = !pf_a ? 0x80000000u : A_KC ? (unsigned)(((w + 4 * (lane_in >> 3)) * 8 + (lane_in & 7)) * g.lda) * 2u : (unsigned)(lane_in * g.lda) * 2u + (unsigned)w * 128u;
+    const unsigned pfb = !pf_b ? 0x80000000u : B_KC ? (unsigned)(gather_row((w + 4 * (lane_in >> 3)) * 8 + (lane_in & 7), swi) * g.ldb) * 2u : (unsigned)(lane_in * g.ldb) * 2u + (unsigned)w * 128u;
     const unsigned a0 = ra.w0, a1 = ra.w1, a2 = ra.w2, b0 = rb.w0, b1 = rb.w1, b2 = rb.w2;
     const unsigned rda0 = rda_lo + st, rda1 = A_KC ? rda_hi + st : rda_hi, rdb0 = rdb_lo + st;
     const unsigned dst = w4_sgpr(st + (unsigned)w * 1024u);
     if constexpr (B_KC) {
       const unsigned rdb1 = rdb_hi + st;
-      MM_W4_RUN_NT(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, nkm1_s, vrag, vrag)
+      MM_W4_RUN_NT(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, pfa, pfb, nkm1_s, vrag, vrag)
 #ifdef MM_W4_DIAG
-      MM_W4_RUN_NT_DIAG(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, nkm1_s, vrag, vrag)
+      MM_W4_RUN_NT_DIAG(SCHED, voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, pfa, pfb, nkm1_s, vrag, vrag)
       if constexpr (SCHED == 121) {
         unsigned o0, o1, o2, o3, o4;
         asm volatile(MM_W4_ASM_NT_S121
                      : [o0] "=&s"(o0), [o1] "=&s"(o1), [o2] "=&s"(o2), [o3] "=&s"(o3), [o4] "=&s"(o4)
-                     : MM_W4_INPUTS_NT(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, nkm1_s, vrag, vrag)
+                     : MM_W4_INPUTS_NT(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, tb1, tb2, nk_s, dst, wv_s, pfa, pfb, nkm1_s, vrag, vrag)
                      : MM_W4_CLOBBERS_DIAG);
         if (l == 0 && blockIdx.x < 256) {
           unsigned* d = g_w4_diag + (blockIdx.x * 4 + w) * 4;
@@ -1606,15 +1617,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
 #endif
     } else if constexpr (A_KC) {
       const unsigned rdb1 = rdb_hi;
-      MM_W4_RUN_NN(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s, nkm1_s, vrag)
+      MM_W4_RUN_NN(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s, pfa, pfb, nkm1_s, vrag)
 #ifdef MM_W4_DIAG
-      MM_W4_RUN_NN_DIAG(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s, nkm1_s, vrag)
+      MM_W4_RUN_NN_DIAG(SCHED, voffa0, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s, pfa, pfb, nkm1_s, vrag)
 #endif
     } else {
       const unsigned rdb1 = rdb_hi;
-      MM_W4_RUN_TN(SCHED, voffa0, voffa1, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s)
+      MM_W4_RUN_TN(SCHED, voffa0, voffa1, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s, pfa, pfb)
 #ifdef MM_W4_DIAG
-      MM_W4_RUN_TN_DIAG(SCHED, voffa0, voffa1, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s)
+      MM_W4_RUN_TN_DIAG(SCHED, voffa0, voffa1, rda0, rda1, voffb0, voffb1, rdb0, rdb1, a0, a1, a2, b0, b1, b2, na0, na1, na2, nb0, nb1, nb2, ta, tb0, nk_s, dst, wv_s, pfa, pfb)
 #endif
     }
     sidx += (unsigned)nk;
@@ -1709,17 +1720,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
       }
       const unsigned voffa0 = toa[0], voffa1 = toa[1], voffb0 = tob[0];
       const unsigned vrag = rag_mask(lane_in);
+      const unsigned pfa = 0u, pfb = 0u;            // (no L2 prefetch in the half-tile loop)
       const unsigned a0 = ha.w0, a1 = ha.w1, a2 = ha.w2, b0 = hb.w0, b1 = hb.w1, b2 = hb.w2;
       const unsigned z = w4_sgpr(0u);
       const unsigned rda0 = rda_lo, rda1 = rda_hi, rdb0 = rdb_lo, rdb1 = rdb_hi;      // stage 0
       const unsigned dst = w4_sgpr((unsigned)w * 1024u);
       const unsigned tbh0 = B_KC ? w4_sgpr(32u * ldb2) : w4_sgpr(16u * ldb2), tbh1 = w4_sgpr(64u * ldb2);
       if constexpr (B_KC)
-        asm volatile(MM_W4_ASM_NT_H : : MM_W4_INPUTS_NT_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, tbh1, tbh1, nk_s, dst, wv_s, nkm1_s, vrag, vrag) : MM_W4_CLOBBERS);
+        asm volatile(MM_W4_ASM_NT_H : : MM_W4_INPUTS_NT_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, tbh1, tbh1, nk_s, dst, wv_s, pfa, pfb, nkm1_s, vrag, vrag) : MM_W4_CLOBBERS);
       else if constexpr (A_KC)
-        asm volatile(MM_W4_ASM_NN_H : : MM_W4_INPUTS_NN_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s, nkm1_s, vrag) : MM_W4_CLOBBERS);
+        asm volatile(MM_W4_ASM_NN_H : : MM_W4_INPUTS_NN_H(voffa0, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s, pfa, pfb, nkm1_s, vrag) : MM_W4_CLOBBERS);
       else
-        asm volatile(MM_W4_ASM_TN_H : : MM_W4_INPUTS_TN_H(voffa0, voffa1, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s) : MM_W4_CLOBBERS);
+        asm volatile(MM_W4_ASM_TN_H : : MM_W4_INPUTS_TN_H(voffa0, voffa1, rda0, rda1, voffb0, rdb0, rdb1, a0, a1, a2, b0, b1, b2, z, z, z, z, z, z, ta, tbh0, nk_s, dst, wv_s, pfa, pfb) : MM_W4_CLOBBERS);
       int lane = l;
       asm volatile("" : "+v"(lane));
       const int mw = hm0 + wm * 128, nw = hn0 + wn * 64;
@@ -2638,9 +2650,9 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
   } while (0)
 #define MM_W4_CASE(AKC, BKC, SCHED) case SCHED: MM_LAUNCH_W4(AKC, BKC, 0, SCHED); break;
 #ifdef MM_W4_DIAG
-#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5) MM_W4_CASE(AKC, BKC, 104) MM_W4_CASE(AKC, BKC, 105) MM_W4_CASE(AKC, BKC, 111) MM_W4_CASE(AKC, BKC, 112) MM_W4_CASE(AKC, BKC, 113) MM_W4_CASE(AKC, BKC, 114) MM_W4_CASE(AKC, BKC, 115) MM_W4_CASE(AKC, BKC, 117) MM_W4_CASE(AKC, BKC, 121)
+#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5) MM_W4_CASE(AKC, BKC, 6) MM_W4_CASE(AKC, BKC, 7) MM_W4_CASE(AKC, BKC, 104) MM_W4_CASE(AKC, BKC, 105) MM_W4_CASE(AKC, BKC, 111) MM_W4_CASE(AKC, BKC, 112) MM_W4_CASE(AKC, BKC, 113) MM_W4_CASE(AKC, BKC, 114) MM_W4_CASE(AKC, BKC, 115) MM_W4_CASE(AKC, BKC, 117) MM_W4_CASE(AKC, BKC, 121)
 #else
-#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5)
+#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5) MM_W4_CASE(AKC, BKC, 6) MM_W4_CASE(AKC, BKC, 7)
 #endif
         // schedule: 1 everywhere (one barrier per K-step), except -- "gemm_w4_big" = 4 -- on operands that stream from beyond the
         // Infinity Cache (a wide N or a long K): there the split-barrier schedule 4 (a DMA piece gets 105-168 MFMAs to land instead of
