@@ -51,7 +51,7 @@ const char* mm_error_string(int code);
  * 0|1 (M <= 16 weight-streaming kernel), "gemm_issue_waves" / "attn_issue_waves" 4|8 (how many of a workgroup's 8 waves
  * issue the LDS-DMA), "attn_fwd_waves" 8|4, "attn_dkv_pair" 0|1; round 4: "gemm_w4" 0 | 1 | n (256x256 tiles on the 4-wave
  * hand-scheduled kernel gemm_bf16_w4_kernel: 0 = the 8-wave kernel, 1 = the shipped schedule, n = another schedule of
- * csrc/gen_gemm_w4.py), "gemm_w4_rowmajor" 0|1 (its row-major, LDS-transposed epilogues), "gemm_w4_stream" 0|1 (wait-free plain
+ * csrc/gen_gemm_w4.py: 4 / 5 split barriers, 6 / 7 = 1 / 4 with an L2 prefetch), "gemm_w4_big" 4|1 (schedule 4 where N or K >= 14336: default), "gemm_w4_rowmajor" 0|1 (its row-major, LDS-transposed epilogues), "gemm_w4_stream" 0|1 (wait-free plain
  * epilogue in the accumulator layout), "gemm_w4_shuffle" (0; 1 = the plain epilogue by register lane exchange instead of the LDS round trip: bit-identical, measured equal),
  * "gemm_w4_group_m", "gemm_w4_stagger" / "gemm_w4_stagger_slots" (experiments).  Unknown names return MM_ERR_ARG.   */
 int mm_set_option(const char* name, int value);
