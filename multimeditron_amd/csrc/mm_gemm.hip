@@ -1168,7 +1168,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_dma_kernel(GemmArgs g) {
 // K >= 192 (the host sends anything else to the 8-wave kernel).
 // ------------------------------------------------------------------------------------------------------
 #include "mm_gemm_w4.inc"
+#ifndef MM_W4_DIAG
+#define W4_STAMP(st, i) do { } while (0)
+#endif
 #ifdef MM_W4_DIAG
+__device__ unsigned g_w4_diag2[256 * 4 * 8];       // stamps inside the register-exchange epilogue (W4_STAMP): cycles since the loop's end, summed over tiles
+#define W4_STAMP(st, i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory"); (st)[i] = (unsigned)t_; } while (0)
 __device__ unsigned g_w4_diag[256 * 4 * 7];        // schedule 121: per (workgroup, wave) cycles at the barrier (sum, max), loop cycles, tiles
 #endif
 
@@ -1424,10 +1429,11 @@ __device__ __forceinline__ void w4_epilogue_rowmajor(const GemmArgs& g, char* xp
 // Per row block and 64 columns: 16 accumulator reads, 8 conversions, 4 swaps, ~12 DPP moves, 2 stores -- ~700 instructions per wave
 // and tile, no LDS traffic, no waits.  The value stored is bf16(acc) either way: bit-identical.
 template <int C>
-__device__ __forceinline__ void w4_shuffle_half(const GemmArgs& g, __amdgpu_buffer_rsrc_t rc, int nw, int l) {
+__device__ __forceinline__ void w4_shuffle_half(const GemmArgs& g, __amdgpu_buffer_rsrc_t rc, int nw, int l, unsigned* st = nullptr) {
   f32x4 acc[8][4];
   if constexpr (C == 0) w4_read_acc_c0(acc);
   else w4_read_acc_c1(acc);
+  if (st) W4_STAMP(st, 1 + 2 * C);
   const int r = l & 15, q = l >> 4;
   const int chunk = (r >= 8 ? 4 : 0) + (((q & 1) << 1) | (q >> 1));      // the lane's 16-byte chunk of the 128-byte line
   const int n = nw + C * 64 + chunk * 8;
@@ -1461,14 +1467,16 @@ __device__ __forceinline__ void w4_shuffle_half(const GemmArgs& g, __amdgpu_buff
     __builtin_amdgcn_raw_buffer_store_b128(lo, rc, off, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b128(hi, rc, off8, 0, 0);
   }
+  if (st) W4_STAMP(st, 2 + 2 * C);
 }
 
-__device__ __forceinline__ void w4_epilogue_shuffle(const GemmArgs& g, int mw, int nw, int l) {
+__device__ __forceinline__ void w4_epilogue_shuffle(const GemmArgs& g, int mw, int nw, int l, unsigned* st = nullptr) {
   mw = __builtin_amdgcn_readfirstlane(mw);
   nw = __builtin_amdgcn_readfirstlane(nw);
   auto rc = make_rsrc((const bf16*)g.C + (int64_t)mw * g.ldc, (int64_t)(g.M - mw) * g.ldc * 2);
-  w4_shuffle_half<0>(g, rc, nw, l);
-  w4_shuffle_half<1>(g, rc, nw, l);
+  if (st) W4_STAMP(st, 0);
+  w4_shuffle_half<0>(g, rc, nw, l, st);
+  w4_shuffle_half<1>(g, rc, nw, l, st);
 }
 
 __device__ __forceinline__ unsigned w4_sgpr(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
@@ -1646,6 +1654,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs g) {
       char* xp = smem + 131072 + w * 8192;
 #ifdef MM_W4_DIAG
       if (g.diag_epi & 8) {} else
+#endif
+#ifdef MM_W4_DIAG
+      if (emode == 0 && g.shuffle && !(g.epi & MM_EPI_BIAS)) {
+        unsigned st[5] = {0, 0, 0, 0, 0};
+        w4_epilogue_shuffle(g, mw, n0 + wn * 128, lane, st);
+        if (l == 0 && blockIdx.x < 256)
+          for (int q = 0; q < 5; ++q) g_w4_diag2[(blockIdx.x * 4 + w) * 8 + q] += st[q] - w4_diag_end;
+      } else
 #endif
       if (emode == 0 && g.shuffle && !(g.epi & MM_EPI_BIAS)) w4_epilogue_shuffle(g, mw, n0 + wn * 128, lane);
       else if (emode == 0) w4_epilogue_rowmajor<0>(g, xp, mw, n0 + wn * 128, lane);
@@ -2274,6 +2290,14 @@ int mm_attn_option(const char* name, int value);
 extern int g_adamw_blocks;    // mm_optim.hip
 
 #ifdef MM_W4_DIAG
+extern "C" int mm_w4_diag2_read(unsigned* out, int reset) {     // 256 x 4 x 8 words
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_diag2), sizeof(unsigned) * 256 * 4 * 8) != hipSuccess) return MM_ERR_LAUNCH;
+  if (reset) {
+    static unsigned zeros[256 * 4 * 8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_w4_diag2), zeros, sizeof(zeros)) != hipSuccess) return MM_ERR_LAUNCH;
+  }
+  return MM_OK;
+}
 extern "C" int mm_w4_diag_read(unsigned* out, int reset) {      // diag builds only (not in the ABI header): 256 x 4 x 4 words
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_diag), sizeof(unsigned) * 256 * 4 * 7) != hipSuccess) return MM_ERR_LAUNCH;
   if (reset) {

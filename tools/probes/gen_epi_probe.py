@@ -40,6 +40,13 @@ def seq(var):
             L.append(f"v_permlane16_swap_b32 v{140 + 4 * (p % 4)}, v{142 + 4 * (p % 4)}")
             L.append(f"v_permlane16_swap_b32 v{141 + 4 * (p % 4)}, v{143 + 4 * (p % 4)}")
             L.append(f"buffer_store_dwordx4 v[{140 + 4 * (p % 4)}:{143 + 4 * (p % 4)}], %[vo], %[desc], 0 offen offset:{(p % 4) * 64 + (p // 4) * 512}")
+    elif var == "shuffle_fresh":    # shuffle_all with the stores going to lines nobody has touched for 27 passes (soffset moves 32 MB per pass)
+        for p in range(32):
+            for r in range(8): L.append(f"v_accvgpr_read_b32 v{100 + 8 * (p % 4) + r}, a{8 * p + r}")
+            for r in range(4): L.append(f"v_cvt_pk_bf16_f32 v{140 + 4 * (p % 4) + r}, v{100 + 8 * (p % 4) + 2 * r}, v{101 + 8 * (p % 4) + 2 * r}")
+            L.append(f"v_permlane16_swap_b32 v{140 + 4 * (p % 4)}, v{142 + 4 * (p % 4)}")
+            L.append(f"v_permlane16_swap_b32 v{141 + 4 * (p % 4)}, v{143 + 4 * (p % 4)}")
+            L.append(f"buffer_store_dwordx4 v[{140 + 4 * (p % 4)}:{143 + 4 * (p % 4)}], %[vo2], %[desc], %[so] offen offset:{(p % 2) * 128 + (p // 2) * 256}")
     elif var == "shuffle_nostore":
         for p in range(32):
             for r in range(8): L.append(f"v_accvgpr_read_b32 v{100 + 8 * (p % 4) + r}, a{8 * p + r}")
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void probe_{var}(char* win, int iters, long lo
                : [t0] "=&s"(t0), [t1] "=&s"(t1), [it] "+s"(iters) : [la] "v"(la), [desc] "s"(desc), [vo] "v"(vo), [vo2] "v"(vo2) : "memory", "scc", VCLOB, ACLOB);
   if (l == 0) cyc[blockIdx.x * 4 + w] = t1 - t0;
 }}''')
-    for var in ["shuffle_nostore", "shuffle_all", "accread"]:
+    for var in ["shuffle_nostore", "shuffle_all", "accread", "shuffle_fresh"]:
         body = "\\n".join(seq(var))
         inner = "\\n".join(seq("mfma"))
         out.append(f'''
@@ -94,18 +101,19 @@ __global__ __launch_bounds__(256) void probe_rare_{var}(char* win, int iters, lo
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   unsigned la = (unsigned)(w * 8192 + l * 16);
   i32x4 desc;
-  {{ unsigned long long p = (unsigned long long)(win + (size_t)blockIdx.x * (1 << 20) + w * (1 << 18)); desc[0] = (int)p; desc[1] = (int)(p >> 32); desc[2] = 1 << 18; desc[3] = 0x00020000; }}
+  {{ unsigned long long p = (unsigned long long)(win + (size_t)blockIdx.x * (1 << 17) + w * (1 << 15)); desc[0] = (int)p; desc[1] = (int)(p >> 32); desc[2] = 0x40000000; desc[3] = 0x00020000; }}
   desc[0] = __builtin_amdgcn_readfirstlane(desc[0]); desc[1] = __builtin_amdgcn_readfirstlane(desc[1]);
   desc[2] = __builtin_amdgcn_readfirstlane(desc[2]); desc[3] = __builtin_amdgcn_readfirstlane(desc[3]);
-  unsigned vo = (unsigned)((l & 15) * 8192 + (l >> 4) * 16);
-  unsigned vo2 = (unsigned)((l >> 3) * 8192 + (l & 7) * 16);
+  unsigned vo = (unsigned)((l & 15) * 2048 + (l >> 4) * 16);        // (rare_* kernels: a wave's 32 KB = 16 rows x 2 KB, dense)
+  unsigned vo2 = (unsigned)((l >> 3) * 4096 + (l & 7) * 16);        // 8 rows x 4 KB
   lds[t] = uint4{{0, 0, 0, 0}};
   __syncthreads();
   long long t0, t1, acc = 0;
   for (int it = 0; it < iters; ++it) {{
     int inner = 40;
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(it % 28) << 25);      // + 32 MB per pass
     asm volatile("1:\\n{inner}\\ns_sub_u32 %[it], %[it], 1\\ns_cmp_lg_u32 %[it], 0\\ns_cbranch_scc1 1b\\ns_memtime %[t0]\\ns_waitcnt lgkmcnt(0)\\n{body}\\ns_memtime %[t1]\\ns_waitcnt lgkmcnt(0)\\n"
-                 : [t0] "=&s"(t0), [t1] "=&s"(t1), [it] "+s"(inner) : [la] "v"(la), [desc] "s"(desc), [vo] "v"(vo), [vo2] "v"(vo2) : "memory", "scc", VCLOB, ACLOB);
+                 : [t0] "=&s"(t0), [t1] "=&s"(t1), [it] "+s"(inner) : [la] "v"(la), [desc] "s"(desc), [vo] "v"(vo), [vo2] "v"(vo2), [so] "s"(so) : "memory", "scc", VCLOB, ACLOB);
     acc += t1 - t0;
   }}
   if (l == 0) cyc[blockIdx.x * 4 + w] = acc;
@@ -127,14 +135,14 @@ static void run(const char* name, kern_t k, char* win, long long* cyc, int n_ins
 }
 int main() {
   char* win; long long* cyc;
-  hipMalloc(&win, 256ll << 20); hipMalloc(&cyc, 1024 * 8);
+  hipMalloc(&win, 1100ll << 20); hipMalloc(&cyc, 1024 * 8);
 ''')
     for var in VARS:
         out.append(f'  run("{var}", probe_{var}, win, cyc, {len(seq(var))});')
     for grid in (128, 64, 32, 8):
         out.append(f'  run("store_nowait", probe_store_nowait, win, cyc, 32, {grid});')
         out.append(f'  run("store_rows", probe_store_rows, win, cyc, 32, {grid});')
-    for var in ["shuffle_nostore", "shuffle_all", "accread"]:
+    for var in ["shuffle_nostore", "shuffle_all", "accread", "shuffle_fresh"]:
         out.append(f'  run("rare_{var}", probe_rare_{var}, win, cyc, {len(seq(var))});')
     out.append("  return 0;\n}\n")
     with open("build_diag/epi_probe.hip", "w") as f:

@@ -48,5 +48,13 @@ for M, N, Kd, epi in [(m, n, k, e) for (m, n, k) in SHAPES for e in EPI]:
           f"barrier cycles per K-step: mean {float((wait / tiles / nk).mean()):.0f}, by wave {[round(float((wait[:, w] / tiles[:, w] / nk).mean())) for w in range(4)]}, "
           f"first P of a tile {float((mx / tiles).mean()):.0f} cycles; between two tiles' loops {float((gap / (tiles - 1).clamp(min=1)).mean()):.0f} cycles "
           f"(a tile's loop {float((loop / tiles).mean()):.0f}); loop end -> last epilogue instruction issued {float((epi / tiles).mean()):.0f}", flush=True)
+    if hasattr(L, "mm_w4_diag2_read"):
+        b2 = (ctypes.c_uint * (256 * 4 * 8))()
+        if L.mm_w4_diag2_read(b2, 1) == 0:
+            d2 = torch.tensor(list(b2), dtype=torch.float64).view(256, 4, 8)
+            if float(d2.sum()) > 0:
+                per = (d2[:, :, :5] / tiles.unsqueeze(-1)).mean(dim=(0, 1))
+                print(f"   register-exchange epilogue, cycles since the loop's end (mean): entry {per[0]:.0f}, half 0 accumulators read {per[1]:.0f}, half 0 stored {per[2]:.0f}, "
+                      f"half 1 read {per[3]:.0f}, half 1 stored {per[4]:.0f}")
     for wg in (0, 1, 100):
         print(f"   WG {wg}: wait/K-step by wave {[round(float(wait[wg, w] / tiles[wg, w] / nk)) for w in range(4)]}  loop/K-step {[round(float(loop[wg, w] / tiles[wg, w] / nk)) for w in range(4)]}")
