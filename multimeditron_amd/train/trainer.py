@@ -128,7 +128,10 @@ class MultimodalTrainer:
         n = int(os.environ.get(env, str(_SIDE_CUS_DEFAULT.get(env, 0))))
         if n > 0 and torch.cuda.is_available():
             return K.masked_stream(n, tag=env)
-        lowprio = os.environ.get(env.replace("_CUS", "_PRIO"))          # MM_ADAMW_PRIO / MM_DEFER_PRIO: a HIP stream priority (experiment)
+        # MM_ADAMW_PRIO / MM_DEFER_PRIO: a HIP stream priority (experiment).  Round 4, with the update as short workgroups: the LOWEST priority for
+        # AdamW costs 30 ms per step (377 vs 348: the decoder's GEMMs overtake it and then wait for it); the image tower on a HIGHEST-priority
+        # stream of its own (tried as MM_VIT_PRIO, removed) costs 43 ms (386 vs 343: its backward then preempts the weight-gradient GEMMs)
+        lowprio = os.environ.get(env.replace("_CUS", "_PRIO"))
         if lowprio is not None and torch.cuda.is_available():
             return K.priority_stream(int(lowprio), tag=env)
         return torch.cuda.Stream(priority=priority)
