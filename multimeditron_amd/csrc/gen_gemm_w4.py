@@ -79,10 +79,11 @@ class Sched:
 # builds that drop one ingredient (results wrong by design) to price it.
 SCHEDS = [
     Sched(1, dma0=0, dma_stride=4),                 # shipped: a wave's 16 DMA pieces 4 MFMAs (64 cycles) apart over the whole of phase B
-    Sched(2, dma0=1, dma_stride=2),                 # round-4 first cut (pieces 2 MFMAs apart): -4 % (profiles/r04_gemm_w4.md)
-    Sched(3, dma0=0, dma_stride=4, coarse=False),   # counted lgkmcnt waits instead of one per K-step
+    # (2, 3, 5: earlier candidates, compiled into -DMM_W4_DIAG builds only -- tools/build_diag.sh -- to keep the product's compile time down)
+    Sched(2, dma0=1, dma_stride=2, diag=True),                 # round-4 first cut (pieces 2 MFMAs apart): -4 % (profiles/r04_gemm_w4.md)
+    Sched(3, dma0=0, dma_stride=4, coarse=False, diag=True),   # counted lgkmcnt waits instead of one per K-step
     Sched(4, dma0=2, dma_stride=4, coarse=False, ra=(0, 32), book0=16, split=(44, 20, 5), rb=(21, 53)),
-    Sched(5, dma0=2, dma_stride=4, coarse=False, ra=(0, 30), book0=8, split=(36, 28, 7), rb=(29, 57)),
+    Sched(5, dma0=2, dma_stride=4, coarse=False, ra=(0, 30), book0=8, split=(36, 28, 7), rb=(29, 57), diag=True),
     Sched(6, dma0=0, dma_stride=4, pf=2),                                                      # schedule 1 + L2 prefetch two K-steps ahead of the DMA
     Sched(7, dma0=2, dma_stride=4, coarse=False, ra=(0, 32), book0=16, split=(44, 20, 5), rb=(21, 53), pf=2),      # schedule 4 + the same
     # ---- timing-only builds (-DMM_W4_DIAG, tools/build_diag.sh): each drops one ingredient of schedule 1

@@ -2676,7 +2676,7 @@ static int gemm_launch(GemmArgs g, int dtype, int layout, hipStream_t s) {
 #ifdef MM_W4_DIAG
 #define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5) MM_W4_CASE(AKC, BKC, 6) MM_W4_CASE(AKC, BKC, 7) MM_W4_CASE(AKC, BKC, 104) MM_W4_CASE(AKC, BKC, 105) MM_W4_CASE(AKC, BKC, 111) MM_W4_CASE(AKC, BKC, 112) MM_W4_CASE(AKC, BKC, 113) MM_W4_CASE(AKC, BKC, 114) MM_W4_CASE(AKC, BKC, 115) MM_W4_CASE(AKC, BKC, 117) MM_W4_CASE(AKC, BKC, 121)
 #else
-#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 2) MM_W4_CASE(AKC, BKC, 3) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 5) MM_W4_CASE(AKC, BKC, 6) MM_W4_CASE(AKC, BKC, 7)
+#define MM_W4_CASES(AKC, BKC) MM_W4_CASE(AKC, BKC, 4) MM_W4_CASE(AKC, BKC, 6) MM_W4_CASE(AKC, BKC, 7)
 #endif
         // schedule: 1 everywhere (one barrier per K-step), except -- "gemm_w4_big" = 4 -- on operands that stream from beyond the
         // Infinity Cache (a wide N or a long K): there the split-barrier schedule 4 (a DMA piece gets 105-168 MFMAs to land instead of
