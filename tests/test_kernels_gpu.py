@@ -458,6 +458,19 @@ def test_attention_fwd_bwd(K, dtype, case):
     assert rel(dv.float(), vf.grad) < gtol, "dv"
 
 
+@pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[5] == 128])
+def test_attention_bwd_resident_kv(K, case):
+    """mm_set_option("attn_dkv_res", 1): the D = 128 dK/dV kernel with the wave's K / V fragments resident in registers (four waves, one per
+    SIMD: attn_bwd_dkv128_res_kernel) against the same fp32 reference as the shipped pair kernel.  (Round 4: correct, 1.8x slower -- a wave
+    alone on its SIMD exposes the latencies the second wave hid --, so it stays an option)"""
+    from multimeditron_amd._lib import lib
+    assert lib().mm_set_option(b"attn_dkv_res", 1) == 0
+    try:
+        test_attention_fwd_bwd(K, torch.bfloat16, case)
+    finally:
+        assert lib().mm_set_option(b"attn_dkv_res", 0) == 0
+
+
 @pytest.mark.parametrize("case", [(4, 2051, 32, 8, 128, True), (2, 77, 4, 2, 64, True), (1, 300, 7, 1, 128, False),
                                   (3, 64, 2, 2, 64, False), (2, 1, 8, 1, 128, False), (2, 513, 16, 2, 128, True),
                                   (3, 130, 4, 4, 128, True), (2, 1000, 8, 4, 128, False), (1, 17, 4, 1, 128, True), (4, 2048, 32, 8, 128, False)])

@@ -110,6 +110,40 @@ if "--ab-issue" in sys.argv:     # out-of-phase forward: 4 vs 8 waves issuing th
     run(2, 4096, 32, 8, 128, True)
     run(4, 2048, 32, 8, 128, True, mask=True)
     sys.exit(0)
+if "--ab-res" in sys.argv:       # dK/dV: the paired 8-wave kernel vs K / V fragments resident on four waves (attn_dkv_res), same process
+    def grads(B, S, Hq, Hkv, causal, mask, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        q = torch.randn(B, S, Hq, 128, device="cuda", generator=g).to(torch.bfloat16)
+        k = torch.randn(B, S, Hkv, 128, device="cuda", generator=g).to(torch.bfloat16)
+        v = torch.randn(B, S, Hkv, 128, device="cuda", generator=g).to(torch.bfloat16)
+        do = torch.randn(B, S, Hq, 128, device="cuda", generator=g).to(torch.bfloat16)
+        km = None
+        if mask:
+            km = torch.ones(B, S, dtype=torch.long, device="cuda")
+            km[0, S - 37:] = 0
+        out, lse = K.attn_fwd(q, k, v, km, causal, 128 ** -0.5)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        K.attn_bwd(q, k, v, out, do, lse, km, causal, 128 ** -0.5, dq, dk, dv)
+        return dq.float(), dk.float(), dv.float()
+    for (B, S, Hq, Hkv, causal, mask) in ((4, 2048, 32, 8, True, False), (2, 1000, 8, 2, True, True), (1, 333, 4, 4, False, False), (2, 640, 28, 4, True, False), (1, 2048, 2, 2, True, True)):
+        lib().mm_set_option(b"attn_dkv_res", 0)
+        ref = grads(B, S, Hq, Hkv, causal, mask, 5)
+        lib().mm_set_option(b"attn_dkv_res", 1)
+        got = grads(B, S, Hq, Hkv, causal, mask, 5)
+        rel = [float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(got, ref)]
+        print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} causal={causal} mask={mask}: rel L2 of (dq, dk, dv) vs the pair kernel {rel[0]:.2e} {rel[1]:.2e} {rel[2]:.2e}  max |d dk| {float((got[1] - ref[1]).abs().max()):.3e}", flush=True)
+        assert rel[0] == 0.0 and rel[1] < 4e-3 and rel[2] < 4e-3, rel
+    for v_ in (0, 1, 0, 1, 0, 1):
+        lib().mm_set_option(b"attn_dkv_res", v_)
+        print("attn_dkv_res", v_)
+        run(4, 2048, 32, 8, 128, True)
+    lib().mm_set_option(b"attn_dkv_res", 1)
+    run(2, 4096, 32, 8, 128, True)
+    run(4, 2048, 28, 4, 128, True)
+    lib().mm_set_option(b"attn_dkv_res", 0)
+    run(2, 4096, 32, 8, 128, True)
+    run(4, 2048, 28, 4, 128, True)
+    sys.exit(0)
 if "--ab-dkv" in sys.argv:       # dK/dV fragment ring: 4 slots vs 8 (same process, interleaved)
     run(4, 2048, 32, 8, 128, True)
     for rd, late in ((4, 0), (8, 0), (8, 1), (4, 0), (8, 0), (8, 1), (8, 0), (8, 1)):
