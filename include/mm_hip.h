@@ -49,7 +49,7 @@ const char* mm_error_string(int code);
  * trainer sets 0 under data parallelism), "gemm_kernel" 0 auto | 1 register-staged 128x128 | 2..6 LDS-DMA tiles 256x128,
  * 256x256, 128x128, 64x128, 64x64, "gemm_small" -1 auto | 0..5, "gemm_tail" 0|1 (half-tile last round), "gemm_skinny"
  * 0|1 (M <= 16 weight-streaming kernel), "gemm_issue_waves" / "attn_issue_waves" 4|8 (how many of a workgroup's 8 waves
- * issue the LDS-DMA), "attn_fwd_waves" 8|4, "attn_dkv_pair" 0|1, "attn_dkv_res" 0|1 (round 4: the dK/dV kernel with resident K / V fragments on four waves; slower, off); round 4: "gemm_w4" 0 | 1 | n (256x256 tiles on the 4-wave
+ * issue the LDS-DMA), "attn_fwd_waves" 8|4, "attn_dkv_pair" 0|1, "attn_dkv_res" 0|1|2 (round 4: the dK/dV kernel with resident K / V fragments on four waves, 2 = items pipelined inside the wave; slower, off); round 4: "gemm_w4" 0 | 1 | n (256x256 tiles on the 4-wave
  * hand-scheduled kernel gemm_bf16_w4_kernel: 0 = the 8-wave kernel, 1 = the shipped schedule, n = another schedule of
  * csrc/gen_gemm_w4.py: 4 / 5 split barriers, 6 / 7 = 1 / 4 with an L2 prefetch), "gemm_w4_big" 4|1 (schedule 4 where N or K >= 14336: default), "gemm_w4_rowmajor" 0|1 (its row-major, LDS-transposed epilogues), "gemm_w4_stream" 0|1 (wait-free plain
  * epilogue in the accumulator layout), "gemm_w4_shuffle" (0; 1 = the plain epilogue by register lane exchange instead of the LDS round trip: bit-identical, measured equal),

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "mm_common.h"
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -2212,6 +2213,244 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_res_kernel(AttnArgs a) {
   }
 }
 
+// The same with the items software-pipelined inside the wave (mm_set_option "attn_dkv_res" = 2): iteration `it` runs the S^T / dP^T products
+// of item it + 1 INTERLEAVED with the exp / dS arithmetic of item it (one MFMA, then one of the 16 accumulator elements: the vector ALU works in
+// the matrix pipe's shadow), then the dV / dK products of item it.  The ring has three stages (item it for the transposed fragments, it + 1 for
+// the row fragments, it + 2 landing); fully masked (head, tile) items are not skipped (their p is 0: the sums are unchanged).
+template <int RD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
+  constexpr int BQ = 32, NDB = 4, QT = BQ * 256, IMG = 128 * 256;     // 8 KiB per 32-row tile, 32 KiB per 128-key image
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [V image | K image | 3 stages x (Q | dO) | row constants]
+  const int l = threadIdx.x & 63, h = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: LDS-DMA addresses live in SGPRs
+  const int wt = w, tt = threadIdx.x;
+  float* rowc = (float*)(smem + 2 * IMG + 6 * QT);                     // [3 stages][lse*log2e (32) | delta (32)]
+  // 1-D grid, XCD-aware: the hardware deals consecutive workgroup ids to the 8 XCDs in turn, and the `npair` workgroups of one
+  // (batch, KV head) stream the SAME Q / dO rows (G heads x Sq x 512 B).  With a (pair, head, batch) grid those workgroups sat
+  // on 8 different XCDs, every L2 saw each tile once and the kernel pulled 4.5x its algorithmic bytes from beyond L2.  Here
+  // group g = (b, hkv) lives on XCD g % 8 and its pairs fill that XCD's consecutive slots (needs B * Hkv % 8 == 0, else the
+  // plain order).
+  const int npair = (((a.Skv + 127) / 128) + 1) / 2, ngroup = a.B * a.Hkv;
+  int pair_i, grp;
+  if ((ngroup & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    pair_i = slot % npair;
+    grp = (slot / npair) * 8 + xcd;
+  } else {
+    pair_i = blockIdx.x % npair;
+    grp = blockIdx.x / npair;
+  }
+  const int b = grp / a.Hkv, hkv = grp % a.Hkv;
+  const int G = a.Hq / a.Hkv;
+  const int nkb = (a.Skv + 127) / 128;
+  const int shift = a.Skv - a.Sq;
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const unsigned ring0 = lds0 + 2 * IMG;
+  const float sc = a.scale * LOG2E;
+  const int nqt = (a.Sq + BQ - 1) / BQ;
+  const int64_t do_ss = (int64_t)a.Hq * 128;
+  const ImgaBases bases = imga_bases(smem, 0);
+  // per-lane bases: key images at this wave's 32 keys (row fragments), this team's ring (row + transposed fragments)
+  const char* vrow[2] = {bases.kr[0] + 2048 * 4 * wt, bases.kr[1] + 2048 * 4 * wt};
+  const char* ring_r[2] = {bases.kr[0] + 2 * IMG, bases.kr[1] + 2 * IMG};
+  const char* ring_t[2] = {bases.vt[0] + 2 * IMG, bases.vt[1] + 2 * IMG};
+  // DMA source patterns (image (a)): a 1-KiB piece = 8 rows x 128 B, lane pattern s = (piece >> 1) & 1
+  unsigned lk[2], lv[2], lq, ldo;
+  imga_lane_patterns(lk, lv, a.k_ss, a.v_ss);
+  {
+    const int rl = (l >> 2) & 7, cl = 4 * (l >> 5) + ((l & 3) ^ (((wt & 1) << 1) | ((l >> 4) & 1)));   // this wave's ring pieces: 2wt, 2wt+1
+    lq = (unsigned)((int64_t)rl * a.q_ss * 2 + cl * 16);
+    ldo = (unsigned)((int64_t)rl * do_ss * 2 + cl * 16);
+  }
+
+  for (int pass = 0; pass < 2; ++pass) {
+    const int kb = pass == 0 ? pair_i : nkb - 1 - pair_i;
+    if (pass == 1 && kb <= pair_i) break;                    // odd count: the middle block has no partner
+    const int kblk = kb * 128;
+    const int k0 = kblk + wt * 32;
+    const int ki = k0 + (l & 31);
+    {   // V and K images of the 128 keys: 32 pieces each, 8 per wave (four waves)
+      const SRsrc rv = rows_rsrc((const bf16*)a.v + b * a.v_sb + hkv * a.v_sh, a.Skv, a.v_ss);
+      const SRsrc rk = rows_rsrc((const bf16*)a.k + b * a.k_sb + hkv * a.k_sh, a.Skv, a.k_ss);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pc = w * 8 + i, prow = kblk + 8 * (pc >> 1);
+        lds_dma16(rv, lv[(i >> 1) & 1] + (unsigned)((int64_t)prow * a.v_ss * 2 + (i & 1) * 128), lds0 + pc * 1024);
+        lds_dma16(rk, lk[(i >> 1) & 1] + (unsigned)((int64_t)prow * a.k_ss * 2 + (i & 1) * 128), lds0 + IMG + pc * 1024);
+      }
+    }
+    bool kvalid = ki < a.Skv;
+    if (kvalid && a.kmask) kvalid = a.kmask[(int64_t)b * a.Skv + ki] != 0;
+    f32x16 dk_acc[NDB], dv_acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk_acc[i][r] = 0.f; dv_acc[i][r] = 0.f; }
+
+    int qt0 = 0;
+    if (a.causal) qt0 = max(0, kblk - shift) / BQ;
+    const int per_head = max(0, nqt - qt0);
+    // the group's (query head, query tile) items in head-major order: all of them
+    const int total = per_head * G, niter = total;
+    constexpr int item0 = 0;
+    float rc = 0.f;
+    auto issue = [&](int it) {
+      const int idx = item0 + it;
+      if (idx >= total || (MM_DKV_DIAG & 1)) return;
+      const int g = idx / per_head, qb = (qt0 + idx % per_head) * BQ;
+      const int hq = hkv * G + g;
+      const SRsrc rq = rows_rsrc((const bf16*)a.q + b * a.q_sb + hq * a.q_sh, a.Sq, a.q_ss);
+      const SRsrc rdo = rows_rsrc((const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128, a.Sq, do_ss);
+      const unsigned st = ring0 + (unsigned)((it % 3) * 2 * QT) + (unsigned)(wt * 2) * 1024u;
+      const int prow = qb + 8 * wt;                                    // this wave's two pieces of each tile: rows 8wt .. 8wt+7
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        lds_dma16(rq, lq + (unsigned)((int64_t)prow * a.q_ss * 2 + i * 128), st + i * 1024);
+        lds_dma16(rdo, ldo + (unsigned)((int64_t)prow * do_ss * 2 + i * 128), st + QT + i * 1024);
+      }
+      if (tt < 64) {
+        const int qq = qb + (tt & 31);
+        const int64_t ro = ((int64_t)b * a.Hq + hq) * a.Sq + qq;
+        if (tt < 32) rc = qq < a.Sq ? a.lse[ro] * LOG2E : INFINITY;
+        else rc = qq < a.Sq ? a.delta[ro] : 0.f;
+      }
+    };
+    if (niter > 0) {
+      issue(0);
+      if (tt < 64) rowc[tt] = rc;
+    }
+    if (niter > 1) issue(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the images and the first two tiles have landed ...
+    __builtin_amdgcn_s_barrier();                                      // ... in every wave
+    if (niter > 1 && tt < 64) rowc[64 + tt] = rc;
+    bf16x8 kres[8], vres[8];                                           // this wave's 32 keys: K / V rows x 16 d per fragment, the whole pass
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) {
+      kres[ds] = *(const bf16x8*)(vrow[ds & 1] + IMG + 512 * (ds >> 1));
+      vres[ds] = *(const bf16x8*)(vrow[ds & 1] + 512 * (ds >> 1));
+    }
+    constexpr int LA = RD == 8 ? 6 : 3;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s_cur = zero16, dp_cur = zero16;
+    // row fragment j (< 16) of the tile in ring stage offset `sr`: k-step j >> 1, kind j & 1 (0: Q rows, 1: dO rows);
+    // transposed fragment j (>= 16) of the tile at `stt`: d block (j - 16) >> 2, 16-query step ((j - 16) >> 1) & 1, kind j & 1 (0: dO^T, 1: Q^T)
+    auto frag = [&](int j, int sr, int stt) -> bf16x8 {
+      if (j < 16) {
+        const int ds = j >> 1, a2 = ds & 1, off = 512 * (ds >> 1);
+        if ((j & 1) == 0) return *(const bf16x8*)(ring_r[a2] + sr + off);
+        return *(const bf16x8*)(ring_r[a2] + sr + QT + off);
+      }
+      const int jj = j - 16, db = jj >> 2, s16 = (jj >> 1) & 1, kind = jj & 1;
+      const int off = stt + (kind == 0 ? QT : 0) + 4096 * s16 + 512 * db;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, ring_t[0] + off));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, ring_t[1] + off));
+      bf16x8 o;
+      o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+      o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+      return o;
+    };
+    bf16x8 fr[RD];                                                     // ring: fragment j lives in fr[j % RD]
+    if (niter > 0) {                                                   // pipeline prologue: S^T / dP^T of item 0
+#pragma unroll
+      for (int j = 0; j < LA; ++j) fr[j] = frag(j, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        if (m & 1) dp_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % RD], vres[m >> 1], m > 1 ? dp_cur : zero16, 0, 0, 0);
+        else s_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % RD], kres[m >> 1], m > 1 ? s_cur : zero16, 0, 0, 0);
+        if (m + LA < 16) fr[(m + LA) % RD] = frag(m + LA, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    for (int it = 0; it < niter; ++it) {
+      const int qb = (qt0 + it % per_head) * BQ;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tile it + 1 (requested an iteration ago) has landed ...
+      __builtin_amdgcn_s_barrier();                                    // ... in every wave, and every wave has left iteration it - 1 (stage (it + 2) % 3 is free)
+      if (it + 2 < niter) issue(it + 2);
+      const bool nxt = it + 1 < niter;
+      const int so_c = (it % 3) * 2 * QT, so_n = ((it + 1) % 3) * 2 * QT;
+      const float* rcs = rowc + (it % 3) * 64;
+      // row constants of the lane's 16 query rows: rows 8g + 4h + (0..3), g = 0..3 -> 4 + 4 vectors of 16 bytes
+      f32x4 lsev[4], dltv[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        lsev[g4] = *(const f32x4*)(rcs + 8 * g4 + 4 * h);
+        dltv[g4] = *(const f32x4*)(rcs + 32 + 8 * g4 + 4 * h);
+      }
+      f32x16 s_nxt = zero16, dp_nxt = zero16;
+      bf16x8 pf[2], dsf[2];
+      // fragment sequence of this iteration: 0 .. 15 = row fragments of item it + 1 (when there is one), 16 .. 31 = transposed fragments of item it
+      if (nxt) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) fr[j] = frag(j, so_n, so_c);
+      }
+      __builtin_amdgcn_s_setprio(1);
+      // (branch-free bodies: a scalar branch per element ends the basic block, and the compiler then waits lgkmcnt(0) -- the whole fragment
+      // ring -- in front of every MFMA; the mask is a select, and `nxt` picks one of two instantiations per iteration)
+      const bool causal_b = a.causal != 0;
+      auto bc = [&](auto nxt_c) {
+        constexpr bool NXT = decltype(nxt_c)::value;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {                                 // one product of item it + 1, then one accumulator element of item it
+          if constexpr (NXT) {
+            if (m & 1) dp_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % RD], vres[m >> 1], m > 1 ? dp_nxt : zero16, 0, 0, 0);
+            else s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % RD], kres[m >> 1], m > 1 ? s_nxt : zero16, 0, 0, 0);
+            if (m + LA < 16) fr[(m + LA) % RD] = frag(m + LA, so_n, so_c);
+          }
+          if (m + LA >= 16 && m + LA < 20) fr[(m + LA) % RD] = frag(m + LA, so_n, so_c);     // the first four transposed fragments of item it
+          {
+            const int r = m;
+            const int ql = acc_row(r, h);
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[r], sc, -lsev[r >> 2][r & 3]));
+            const bool ok = kvalid && (!causal_b || ki <= (qb + ql + shift));
+            p = ok ? p : 0.f;
+            const float dsv = p * (dp_cur[r] - dltv[r >> 2][r & 3]) * a.scale;
+            pf[r >> 3][r & 7] = (bf16)p;
+            dsf[r >> 3][r & 7] = (bf16)dsv;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (nxt) bc(std::true_type{});
+      else bc(std::false_type{});
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {                                   // fragment 16 + m: d block m >> 2, query step (m >> 1) & 1
+        const int db = m >> 2, s16 = (m >> 1) & 1;
+        if (m & 1) dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(16 + m) % RD], dsf[s16], dk_acc[db], 0, 0, 0);
+        else dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(16 + m) % RD], pf[s16], dv_acc[db], 0, 0, 0);
+        if (16 + m + 4 < 32) fr[(16 + m + 4) % RD] = frag(16 + m + 4, so_n, so_c);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      s_cur = s_nxt;
+      dp_cur = dp_nxt;
+      if (it + 2 < niter && tt < 64) rowc[((it + 2) % 3) * 64 + tt] = rc;
+    }
+    // ---- every wave stores the dK / dV rows of its 32 keys
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                   // every wave has left the ring and the images (the next pass overwrites them)
+    {
+      if (ki < a.Skv) {
+        bf16* dkrow = (bf16*)a.dk + b * a.k_sb + hkv * a.k_sh + (int64_t)ki * a.k_ss;
+        bf16* dvrow = (bf16*)a.dv + b * a.v_sb + hkv * a.v_sh + (int64_t)ki * a.v_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            bf16x4 ok_, ov_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ok_[e] = (bf16)dk_acc[db][rg * 4 + e];
+              ov_[e] = (bf16)dv_acc[db][rg * 4 + e];
+            }
+            *(bf16x4*)(dkrow + db * 32 + 8 * rg + 4 * h) = ok_;
+            *(bf16x4*)(dvrow + db * 32 + 8 * rg + 4 * h) = ov_;
+          }
+      }
+    }
+    __syncthreads();                                                   // `red` is free again before the next pass's DMA
+  }
+}
+
 // dQ for D = 128 with prefetched fragments (same treatment as attn_fwd128p_kernel: image (a), base + constant addressing, a
 // 4-deep fragment ring; same arithmetic and rounding as attn_bwd_dq128_kernel, bit-identical results).  Per 32-key step the
 // wave reads 16 row fragments (K for S^T = K.Q^T, V for dP^T = V.dO^T) and 8 transposed K fragments (dQ^T += K^T.dS^T) -- all
@@ -2888,10 +3127,17 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
           hipLaunchKernelGGL(kern, grid, block, lds, s, a);
         };
         if (g_attn_dkv_res) {                                              // K / V fragments resident, four waves (attn_bwd_dkv128_res_kernel)
-          const size_t lds_r = 2 * 128 * 256 + 4 * 32 * 256 + 2 * 64 * sizeof(float);
-          auto kern = attn_bwd_dkv128_res_kernel<8>;
-          (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
-          hipLaunchKernelGGL(kern, grid, dim3(256), lds_r, s, a);
+          if (g_attn_dkv_res == 2) {                                       // ... with the items pipelined inside the wave (three ring stages)
+            const size_t lds_p = 2 * 128 * 256 + 6 * 32 * 256 + 3 * 64 * sizeof(float);
+            auto kern = attn_bwd_dkv128_resp_kernel<8>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_p, s, a);
+          } else {
+            const size_t lds_r = 2 * 128 * 256 + 4 * 32 * 256 + 2 * 64 * sizeof(float);
+            auto kern = attn_bwd_dkv128_res_kernel<8>;
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds_r, s, a);
+          }
         } else if (g_attn_dkv_rd == 4) launch(attn_bwd_dkv128_pairp_kernel<4, false>);
         else if (g_attn_dkv_late) launch(attn_bwd_dkv128_pairp_kernel<8, true>);
         else launch(attn_bwd_dkv128_pairp_kernel<8, false>);
@@ -2918,7 +3164,7 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
 
 int mm_attn_option(const char* name, int value) {   // reached through mm_set_option (mm_gemm.hip)
   if (!strcmp(name, "attn_dkv_pair")) { g_attn_dkv_pair = value != 0; return MM_OK; }
-  if (!strcmp(name, "attn_dkv_res")) { g_attn_dkv_res = value != 0; return MM_OK; }
+  if (!strcmp(name, "attn_dkv_res")) { if (value < 0 || value > 2) return MM_ERR_ARG; g_attn_dkv_res = value; return MM_OK; }
   if (!strcmp(name, "attn_decode_mfma")) { g_attn_decode_mfma = value != 0; return MM_OK; }
   if (!strcmp(name, "attn_decode_wgs")) { if (value < 1) return MM_ERR_ARG; g_attn_decode_wgs = value; return MM_OK; }
   if (!strcmp(name, "attn_fwd_pf")) { g_attn_fwd_pf = value != 0; return MM_OK; }

@@ -458,13 +458,15 @@ def test_attention_fwd_bwd(K, dtype, case):
     assert rel(dv.float(), vf.grad) < gtol, "dv"
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[5] == 128])
-def test_attention_bwd_resident_kv(K, case):
-    """mm_set_option("attn_dkv_res", 1): the D = 128 dK/dV kernel with the wave's K / V fragments resident in registers (four waves, one per
-    SIMD: attn_bwd_dkv128_res_kernel) against the same fp32 reference as the shipped pair kernel.  (Round 4: correct, 1.8x slower -- a wave
-    alone on its SIMD exposes the latencies the second wave hid --, so it stays an option)"""
+def test_attention_bwd_resident_kv(K, case, mode):
+    """mm_set_option("attn_dkv_res", 1 | 2): the D = 128 dK/dV kernel with the wave's K / V fragments resident in registers (four waves, one per
+    SIMD: attn_bwd_dkv128_res_kernel; 2 = attn_bwd_dkv128_resp_kernel, the items software-pipelined inside the wave over a three-stage ring)
+    against the same fp32 reference as the shipped pair kernel.  (Round 4: both correct, 1.4-1.5x slower than the pair kernel, so they stay
+    options)"""
     from multimeditron_amd._lib import lib
-    assert lib().mm_set_option(b"attn_dkv_res", 1) == 0
+    assert lib().mm_set_option(b"attn_dkv_res", mode) == 0
     try:
         test_attention_fwd_bwd(K, torch.bfloat16, case)
     finally:

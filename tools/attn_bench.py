@@ -128,16 +128,18 @@ if "--ab-res" in sys.argv:       # dK/dV: the paired 8-wave kernel vs K / V frag
     for (B, S, Hq, Hkv, causal, mask) in ((4, 2048, 32, 8, True, False), (2, 1000, 8, 2, True, True), (1, 333, 4, 4, False, False), (2, 640, 28, 4, True, False), (1, 2048, 2, 2, True, True)):
         lib().mm_set_option(b"attn_dkv_res", 0)
         ref = grads(B, S, Hq, Hkv, causal, mask, 5)
-        lib().mm_set_option(b"attn_dkv_res", 1)
-        got = grads(B, S, Hq, Hkv, causal, mask, 5)
-        rel = [float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(got, ref)]
-        print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} causal={causal} mask={mask}: rel L2 of (dq, dk, dv) vs the pair kernel {rel[0]:.2e} {rel[1]:.2e} {rel[2]:.2e}  max |d dk| {float((got[1] - ref[1]).abs().max()):.3e}", flush=True)
-        assert rel[0] == 0.0 and rel[1] < 4e-3 and rel[2] < 4e-3, rel
-    for v_ in (0, 1, 0, 1, 0, 1):
+        for mode in (1, 2):              # 1: resident fragments; 2: + items pipelined inside the wave
+            lib().mm_set_option(b"attn_dkv_res", mode)
+            got = grads(B, S, Hq, Hkv, causal, mask, 5)
+            rel = [float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(got, ref)]
+            print(f"B={B} S={S} Hq={Hq} Hkv={Hkv} causal={causal} mask={mask} attn_dkv_res={mode}: rel L2 of (dq, dk, dv) vs the pair kernel {rel[0]:.2e} {rel[1]:.2e} {rel[2]:.2e}  "
+                  f"max |d dk| {float((got[1] - ref[1]).abs().max()):.3e}", flush=True)
+            assert rel[0] == 0.0 and rel[1] < 4e-3 and rel[2] < 4e-3, rel
+    for v_ in (0, 1, 2, 0, 1, 2, 0, 2):
         lib().mm_set_option(b"attn_dkv_res", v_)
         print("attn_dkv_res", v_)
         run(4, 2048, 32, 8, 128, True)
-    lib().mm_set_option(b"attn_dkv_res", 1)
+    lib().mm_set_option(b"attn_dkv_res", 2)
     run(2, 4096, 32, 8, 128, True)
     run(4, 2048, 28, 4, 128, True)
     lib().mm_set_option(b"attn_dkv_res", 0)
