@@ -2217,14 +2217,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_res_kernel(AttnArgs a) {
 // of item it + 1 INTERLEAVED with the exp / dS arithmetic of item it (one MFMA, then one of the 16 accumulator elements: the vector ALU works in
 // the matrix pipe's shadow), then the dV / dK products of item it.  The ring has three stages (item it for the transposed fragments, it + 1 for
 // the row fragments, it + 2 landing); fully masked (head, tile) items are not skipped (their p is 0: the sums are unchanged).
+// 4 bytes per lane straight into LDS (lane l lands at lds_addr + 4 l): the row constants of the pipelined dK/dV kernel travel like its tiles,
+// so that no compiler-visible load (and the s_waitcnt vmcnt(0) that would come with its use) sits inside the item loop
+__device__ __forceinline__ void lds_dma4(const SRsrc& r, unsigned voff, unsigned lds_addr) {
+  u32x4 d = {r.w0, r.w1, r.w2, r.w3};
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 4\n\t"
+      "buffer_load_dword %1, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(lds_addr), "s"(d)
+      : "memory");
+}
+
 template <int RD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
   constexpr int BQ = 32, NDB = 4, QT = BQ * 256, IMG = 128 * 256;     // 8 KiB per 32-row tile, 32 KiB per 128-key image
-  extern __shared__ __attribute__((aligned(16))) char smem[];          // [V image | K image | 3 stages x (Q | dO) | row constants]
+  constexpr int NST = 5, LAT = 4;                                      // ring stages; tiles requested ahead (tile it + LAT during iteration it)
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // [V image | K image | NST stages x (Q | dO) | NST x row constants (lse 32, -, delta 32, -)]
   const int l = threadIdx.x & 63, h = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: LDS-DMA addresses live in SGPRs
   const int wt = w, tt = threadIdx.x;
-  float* rowc = (float*)(smem + 2 * IMG + 6 * QT);                     // [3 stages][lse*log2e (32) | delta (32)]
+  const unsigned lds0_early = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  float* rowc = (float*)(smem + 2 * IMG + NST * 2 * QT);               // [NST stages][lse (32) | unused (32) | delta (32) | unused (32)] floats
+  const unsigned rowc_lds = lds0_early + 2 * IMG + NST * 2 * QT;
   // 1-D grid, XCD-aware: the hardware deals consecutive workgroup ids to the 8 XCDs in turn, and the `npair` workgroups of one
   // (batch, KV head) stream the SAME Q / dO rows (G heads x Sq x 512 B).  With a (pair, head, batch) grid those workgroups sat
   // on 8 different XCDs, every L2 saw each tile once and the kernel pulled 4.5x its algorithmic bytes from beyond L2.  Here
@@ -2293,7 +2312,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
     // the group's (query head, query tile) items in head-major order: all of them
     const int total = per_head * G, niter = total;
     constexpr int item0 = 0;
-    float rc = 0.f;
     auto issue = [&](int it) {
       const int idx = item0 + it;
       if (idx >= total || (MM_DKV_DIAG & 1)) return;
@@ -2301,28 +2319,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
       const int hq = hkv * G + g;
       const SRsrc rq = rows_rsrc((const bf16*)a.q + b * a.q_sb + hq * a.q_sh, a.Sq, a.q_ss);
       const SRsrc rdo = rows_rsrc((const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128, a.Sq, do_ss);
-      const unsigned st = ring0 + (unsigned)((it % 3) * 2 * QT) + (unsigned)(wt * 2) * 1024u;
+      const unsigned st = ring0 + (unsigned)((it % NST) * 2 * QT) + (unsigned)(wt * 2) * 1024u;
       const int prow = qb + 8 * wt;                                    // this wave's two pieces of each tile: rows 8wt .. 8wt+7
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         lds_dma16(rq, lq + (unsigned)((int64_t)prow * a.q_ss * 2 + i * 128), st + i * 1024);
         lds_dma16(rdo, ldo + (unsigned)((int64_t)prow * do_ss * 2 + i * 128), st + QT + i * 1024);
       }
-      if (tt < 64) {
-        const int qq = qb + (tt & 31);
-        const int64_t ro = ((int64_t)b * a.Hq + hq) * a.Sq + qq;
-        if (tt < 32) rc = qq < a.Sq ? a.lse[ro] * LOG2E : INFINITY;
-        else rc = qq < a.Sq ? a.delta[ro] : 0.f;
+      if (w == 0) {                                                    // the tile's 32 lse and 32 delta values: two 4-byte-per-lane DMAs (lanes >= 32 out of range)
+        const SRsrc rl = make_srsrc((const float*)a.lse + ((int64_t)b * a.Hq + hq) * a.Sq, (int64_t)a.Sq * 4);      // rows >= Sq read 0 (their Q / dO rows are 0 too)
+        const SRsrc rd = make_srsrc((const float*)a.delta + ((int64_t)b * a.Hq + hq) * a.Sq, (int64_t)a.Sq * 4);
+        const unsigned vo = l < 32 ? (unsigned)(qb + l) * 4u : 0x80000000u;
+        lds_dma4(rl, vo, rowc_lds + (unsigned)((it % NST) * 512));
+        lds_dma4(rd, vo, rowc_lds + (unsigned)((it % NST) * 512 + 256));
       }
     };
-    if (niter > 0) {
-      issue(0);
-      if (tt < 64) rowc[tt] = rc;
-    }
-    if (niter > 1) issue(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the images and the first two tiles have landed ...
+#pragma unroll
+    for (int j = 0; j < LAT; ++j)
+      if (j < niter) issue(j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the images and the first tiles have landed ...
     __builtin_amdgcn_s_barrier();                                      // ... in every wave
-    if (niter > 1 && tt < 64) rowc[64 + tt] = rc;
     bf16x8 kres[8], vres[8];                                           // this wave's 32 keys: K / V rows x 16 d per fragment, the whole pass
 #pragma unroll
     for (int ds = 0; ds < 8; ++ds) {
@@ -2363,18 +2379,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
     }
     for (int it = 0; it < niter; ++it) {
       const int qb = (qt0 + it % per_head) * BQ;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // tile it + 1 (requested an iteration ago) has landed ...
-      __builtin_amdgcn_s_barrier();                                    // ... in every wave, and every wave has left iteration it - 1 (stage (it + 2) % 3 is free)
-      if (it + 2 < niter) issue(it + 2);
+      // tile it + 1 has landed: what is younger than it in this wave's queue are tiles it + 2 .. it + LAT - 1 (4 DMA pieces each, 6 in wave 0)
+      {
+        const int young = min(niter, it + LAT) - min(niter, it + 2);
+        if (young >= 2) { if (w == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        else if (young == 1) { if (w == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                                    // ... in every wave, and every wave has left iteration it - 1 (stage (it + LAT) % NST is free)
+      if (it + LAT < niter) issue(it + LAT);
       const bool nxt = it + 1 < niter;
-      const int so_c = (it % 3) * 2 * QT, so_n = ((it + 1) % 3) * 2 * QT;
-      const float* rcs = rowc + (it % 3) * 64;
-      // row constants of the lane's 16 query rows: rows 8g + 4h + (0..3), g = 0..3 -> 4 + 4 vectors of 16 bytes
+      const int so_c = (it % NST) * 2 * QT, so_n = ((it + 1) % NST) * 2 * QT;
+      const float* rcs = rowc + (it % NST) * 128;
+      // row constants of the lane's 16 query rows: rows 8g + 4h + (0..3), g = 0..3 -> 4 + 4 vectors of 16 bytes (read four at a time inside the
+      // element loop instead: 0.683 vs 0.670 ms, the reads then sit on the critical path)
       f32x4 lsev[4], dltv[4];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        lsev[g4] = *(const f32x4*)(rcs + 8 * g4 + 4 * h);
-        dltv[g4] = *(const f32x4*)(rcs + 32 + 8 * g4 + 4 * h);
+        lsev[g4] = *(const f32x4*)(rcs + 8 * g4 + 4 * h) * LOG2E;
+        dltv[g4] = *(const f32x4*)(rcs + 64 + 8 * g4 + 4 * h);
       }
       f32x16 s_nxt = zero16, dp_nxt = zero16;
       bf16x8 pf[2], dsf[2];
@@ -2387,8 +2410,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
       // (branch-free bodies: a scalar branch per element ends the basic block, and the compiler then waits lgkmcnt(0) -- the whole fragment
       // ring -- in front of every MFMA; the mask is a select, and `nxt` picks one of two instantiations per iteration)
       const bool causal_b = a.causal != 0;
-      auto bc = [&](auto nxt_c) {
-        constexpr bool NXT = decltype(nxt_c)::value;
+      const bool need_mask = (__ballot(kvalid) != ~0ull) || (a.causal && (k0 + 31) > (qb + shift));     // wave-uniform: most tiles need none
+      auto bc = [&](auto nxt_c, auto mask_c) {
+        constexpr bool NXT = decltype(nxt_c)::value, MASK = decltype(mask_c)::value;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {                                 // one product of item it + 1, then one accumulator element of item it
           if constexpr (NXT) {
@@ -2396,13 +2420,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
             else s_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[m % RD], kres[m >> 1], m > 1 ? s_nxt : zero16, 0, 0, 0);
             if (m + LA < 16) fr[(m + LA) % RD] = frag(m + LA, so_n, so_c);
           }
-          if (m + LA >= 16 && m + LA < 20) fr[(m + LA) % RD] = frag(m + LA, so_n, so_c);     // the first four transposed fragments of item it
+          if (m + LA >= 16 && m + LA < 16 + LA) fr[(m + LA) % RD] = frag(m + LA, so_n, so_c);   // the first LA transposed fragments of item it
           {
             const int r = m;
-            const int ql = acc_row(r, h);
             float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[r], sc, -lsev[r >> 2][r & 3]));
-            const bool ok = kvalid && (!causal_b || ki <= (qb + ql + shift));
-            p = ok ? p : 0.f;
+            if constexpr (MASK) {
+              const int ql = acc_row(r, h);
+              const bool ok = kvalid && (!causal_b || ki <= (qb + ql + shift));
+              p = ok ? p : 0.f;
+            }
             const float dsv = p * (dp_cur[r] - dltv[r >> 2][r & 3]) * a.scale;
             pf[r >> 3][r & 7] = (bf16)p;
             dsf[r >> 3][r & 7] = (bf16)dsv;
@@ -2410,20 +2436,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       };
-      if (nxt) bc(std::true_type{});
-      else bc(std::false_type{});
+      if (nxt) { if (need_mask) bc(std::true_type{}, std::true_type{}); else bc(std::true_type{}, std::false_type{}); }
+      else { if (need_mask) bc(std::false_type{}, std::true_type{}); else bc(std::false_type{}, std::false_type{}); }
 #pragma unroll
       for (int m = 0; m < 16; ++m) {                                   // fragment 16 + m: d block m >> 2, query step (m >> 1) & 1
         const int db = m >> 2, s16 = (m >> 1) & 1;
         if (m & 1) dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(16 + m) % RD], dsf[s16], dk_acc[db], 0, 0, 0);
         else dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(16 + m) % RD], pf[s16], dv_acc[db], 0, 0, 0);
-        if (16 + m + 4 < 32) fr[(16 + m + 4) % RD] = frag(16 + m + 4, so_n, so_c);
+        if (16 + m + LA < 32) fr[(16 + m + LA) % RD] = frag(16 + m + LA, so_n, so_c);      // (LA = 6 ahead: a transposed fragment is two LDS reads, ~200 cycles)
         __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_s_setprio(0);
       s_cur = s_nxt;
       dp_cur = dp_nxt;
-      if (it + 2 < niter && tt < 64) rowc[((it + 2) % 3) * 64 + tt] = rc;
     }
     // ---- every wave stores the dK / dV rows of its 32 keys
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3128,7 +3153,7 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
         };
         if (g_attn_dkv_res) {                                              // K / V fragments resident, four waves (attn_bwd_dkv128_res_kernel)
           if (g_attn_dkv_res == 2) {                                       // ... with the items pipelined inside the wave (three ring stages)
-            const size_t lds_p = 2 * 128 * 256 + 6 * 32 * 256 + 3 * 64 * sizeof(float);
+            const size_t lds_p = 2 * 128 * 256 + 5 * 2 * 32 * 256 + 5 * 512;
             auto kern = attn_bwd_dkv128_resp_kernel<8>;
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
             hipLaunchKernelGGL(kern, grid, dim3(256), lds_p, s, a);

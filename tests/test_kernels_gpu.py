@@ -463,7 +463,7 @@ def test_attention_fwd_bwd(K, dtype, case):
 def test_attention_bwd_resident_kv(K, case, mode):
     """mm_set_option("attn_dkv_res", 1 | 2): the D = 128 dK/dV kernel with the wave's K / V fragments resident in registers (four waves, one per
     SIMD: attn_bwd_dkv128_res_kernel; 2 = attn_bwd_dkv128_resp_kernel, the items software-pipelined inside the wave over a three-stage ring)
-    against the same fp32 reference as the shipped pair kernel.  (Round 4: both correct, 1.4-1.5x slower than the pair kernel, so they stay
+    against the same fp32 reference as the shipped pair kernel.  (Round 4: both correct, 1.5x / 1.1x the pair kernel's time, so they stay
     options)"""
     from multimeditron_amd._lib import lib
     assert lib().mm_set_option(b"attn_dkv_res", mode) == 0
