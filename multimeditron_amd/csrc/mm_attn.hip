@@ -2312,10 +2312,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
     // the group's (query head, query tile) items in head-major order: all of them
     const int total = per_head * G, niter = total;
     constexpr int item0 = 0;
+    // (head, tile) of the next item to request / to compute: counters instead of idx / per_head and idx % per_head -- two scalar divisions per
+    // item are ~100 instructions that a wave alone on its SIMD cannot hide
+    int is_g = 0, is_q = 0, cq = 0;
     auto issue = [&](int it) {
       const int idx = item0 + it;
       if (idx >= total || (MM_DKV_DIAG & 1)) return;
-      const int g = idx / per_head, qb = (qt0 + idx % per_head) * BQ;
+      const int g = is_g, qb = (qt0 + is_q) * BQ;
+      if (++is_q == per_head) { is_q = 0; ++is_g; }
       const int hq = hkv * G + g;
       const SRsrc rq = rows_rsrc((const bf16*)a.q + b * a.q_sb + hq * a.q_sh, a.Sq, a.q_ss);
       const SRsrc rdo = rows_rsrc((const bf16*)a.dout + ((int64_t)b * a.Sq * a.Hq + hq) * 128, a.Sq, do_ss);
@@ -2378,7 +2382,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
       }
     }
     for (int it = 0; it < niter; ++it) {
-      const int qb = (qt0 + it % per_head) * BQ;
+      const int qb = (qt0 + cq) * BQ;
+      if (++cq == per_head) cq = 0;
       // tile it + 1 has landed: what is younger than it in this wave's queue are tiles it + 2 .. it + LAT - 1 (4 DMA pieces each, 6 in wave 0)
       {
         const int young = min(niter, it + LAT) - min(niter, it + 2);
