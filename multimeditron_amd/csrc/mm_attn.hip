@@ -3159,9 +3159,15 @@ int launch_bf16_bwd(const AttnArgs& a, hipStream_t s) {
         if (g_attn_dkv_res) {                                              // K / V fragments resident, four waves (attn_bwd_dkv128_res_kernel)
           if (g_attn_dkv_res == 2) {                                       // ... with the items pipelined inside the wave (three ring stages)
             const size_t lds_p = 2 * 128 * 256 + 5 * 2 * 32 * 256 + 5 * 512;
-            auto kern = attn_bwd_dkv128_resp_kernel<8>;
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds_p, s, a);
+            if (g_attn_dkv_rd == 4) {                                     // ("attn_dkv_rd" 4: a 4-slot fragment ring, 3 in flight)
+              auto kern = attn_bwd_dkv128_resp_kernel<4>;
+              (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+              hipLaunchKernelGGL(kern, grid, dim3(256), lds_p, s, a);
+            } else {
+              auto kern = attn_bwd_dkv128_resp_kernel<8>;
+              (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+              hipLaunchKernelGGL(kern, grid, dim3(256), lds_p, s, a);
+            }
           } else {
             const size_t lds_r = 2 * 128 * 256 + 4 * 32 * 256 + 2 * 64 * sizeof(float);
             auto kern = attn_bwd_dkv128_res_kernel<8>;

@@ -140,6 +140,11 @@ if "--ab-res" in sys.argv:       # dK/dV: the paired 8-wave kernel vs K / V frag
         print("attn_dkv_res", v_)
         run(4, 2048, 32, 8, 128, True)
     lib().mm_set_option(b"attn_dkv_res", 2)
+    lib().mm_set_option(b"attn_dkv_rd", 4)
+    print("attn_dkv_res 2, attn_dkv_rd 4")
+    run(4, 2048, 32, 8, 128, True)
+    run(4, 2048, 32, 8, 128, True)
+    lib().mm_set_option(b"attn_dkv_rd", 8)
     run(2, 4096, 32, 8, 128, True)
     run(4, 2048, 28, 4, 128, True)
     lib().mm_set_option(b"attn_dkv_res", 0)
