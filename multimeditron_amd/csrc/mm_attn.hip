@@ -2354,16 +2354,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
     f32x16 s_cur = zero16, dp_cur = zero16;
     // row fragment j (< 16) of the tile in ring stage offset `sr`: k-step j >> 1, kind j & 1 (0: Q rows, 1: dO rows);
     // transposed fragment j (>= 16) of the tile at `stt`: d block (j - 16) >> 2, 16-query step ((j - 16) >> 1) & 1, kind j & 1 (0: dO^T, 1: Q^T)
-    auto frag = [&](int j, int sr, int stt) -> bf16x8 {
+    // (the stage offsets are added to the four lane bases ONCE per item -- rr0 / rr1 / rt0 / rt1 below --, so that every read is base + constant:
+    // with `ring + stage + offset` per read the compiler spent two vector adds on each of the 32 transposed reads of an item)
+    const char *rr0 = ring_r[0], *rr1 = ring_r[1], *rt0 = ring_t[0], *rt1 = ring_t[1];
+    auto frag = [&](int j, int, int) -> bf16x8 {
       if (j < 16) {
-        const int ds = j >> 1, a2 = ds & 1, off = 512 * (ds >> 1);
-        if ((j & 1) == 0) return *(const bf16x8*)(ring_r[a2] + sr + off);
-        return *(const bf16x8*)(ring_r[a2] + sr + QT + off);
+        const int ds = j >> 1, off = 512 * (ds >> 1);
+        const char* rb = (ds & 1) ? rr1 : rr0;
+        if ((j & 1) == 0) return *(const bf16x8*)(rb + off);
+        return *(const bf16x8*)(rb + QT + off);
       }
       const int jj = j - 16, db = jj >> 2, s16 = (jj >> 1) & 1, kind = jj & 1;
-      const int off = stt + (kind == 0 ? QT : 0) + 4096 * s16 + 512 * db;
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, ring_t[0] + off));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, ring_t[1] + off));
+      const int off = (kind == 0 ? QT : 0) + 4096 * s16 + 512 * db;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, rt0 + off));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, rt1 + off));
       bf16x8 o;
       o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
       o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
@@ -2395,6 +2399,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv128_resp_kernel(AttnArgs a) {
       if (it + LAT < niter) issue(it + LAT);
       const bool nxt = it + 1 < niter;
       const int so_c = (it % NST) * 2 * QT, so_n = ((it + 1) % NST) * 2 * QT;
+      rr0 = ring_r[0] + so_n; rr1 = ring_r[1] + so_n; rt0 = ring_t[0] + so_c; rt1 = ring_t[1] + so_c;
       const float* rcs = rowc + (it % NST) * 128;
       // row constants of the lane's 16 query rows: rows 8g + 4h + (0..3), g = 0..3 -> 4 + 4 vectors of 16 bytes (read four at a time inside the
       // element loop instead: 0.683 vs 0.670 ms, the reads then sit on the critical path)
